@@ -1,0 +1,153 @@
+/* krotov_hip.h -- C ABI of libkrotov_hip.so, the MI355X (gfx950) engine for the hot path of
+ * Krotov's method: forward propagation -> backward co-state propagation -> sequential
+ * pulse-update sweep, batched over an ensemble of trajectories.
+ *
+ * Reference interfaces replaced (paths under /root/reference):
+ *   src/optimize.jl:247-265  krotov_initial_fw_prop!     -> kr_forward
+ *   src/optimize.jl:303-317  backward sweep              -> kr_backward
+ *   src/optimize.jl:321-370  update + forward sweep      -> kr_update_forward
+ *   src/optimize.jl:279-371  krotov_iteration            -> kr_iteration
+ *   src/workspace.jl:128-161 storages + fw/bw propagators-> kr_create (device-resident)
+ *   src/optimize.jl:332-334  get_from_storage[!]         -> kr_read_storage
+ *   src/optimize.jl:297-302,381-386  chi(T) / tau / J_T for the standard functionals
+ *                                                        -> kr_iteration_functional (device side)
+ * The fine-grained per-trajectory/per-step API the reference consumes (prop_step!,
+ * reinit_prop!, write_to_storage!, dot(chi, mu, psi): optimize.jl:251-263,306-315,346,361-367)
+ * is NOT exported one-to-one: it would mean 2*K*N_T foreign calls per iteration with a host
+ * reduction between steps.  The engine owns whole sweeps.
+ *
+ * Conventions
+ *   - every function returns an int status (KR_OK = 0); nothing throws, aborts or longjmps
+ *     across the boundary.  kr_last_error() gives the message (the Julia shim turns it into an
+ *     ErrorException, which optimize.jl:218-226 already captures).
+ *   - operators: N*N complex128, COLUMN-major, interleaved (re,im) = Julia Matrix{ComplexF64}.
+ *   - states: [K][N] complex128 interleaved, trajectory-major (one Vector{ComplexF64} after the
+ *     other).  pulses / update shapes: [L][N_T] float64 (values on the N_T intervals,
+ *     workspace.jl:37-43,118-125).
+ *   - the caller owns every host array and keeps it alive for the duration of the call
+ *     (GC.@preserve).  The library copies in/out, owns all device memory behind the handle and
+ *     never returns a device pointer.  Pulses are re-read from the caller on every call
+ *     (callbacks may mutate them between iterations: optimize.jl:113-119,
+ *     test/test_iterations.jl:125-143); input arrays are never written
+ *     (test/test_pulse_optimization.jl:33-35).
+ *   - a handle is not re-entrant: one call at a time per handle (calls block until done).
+ *   - the *_dev entry points take DEVICE pointers (same layouts) and enqueue on the handle's
+ *     stream without synchronising; they exist so that whole iterations chain in HBM.
+ */
+#ifndef KROTOV_HIP_H
+#define KROTOV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KR_ABI_VERSION 1
+
+enum kr_status {
+    KR_OK = 0,
+    KR_ERR_INVALID = 1,     /* bad argument / configuration (e.g. L = 0: workspace.jl:71-73)   */
+    KR_ERR_NO_DEVICE = 2,   /* no usable HIP device -- there is NO CPU fallback                */
+    KR_ERR_HIP = 3,         /* a HIP runtime call failed                                       */
+    KR_ERR_UNSUPPORTED = 4, /* valid request outside what this build implements                */
+    KR_ERR_TIMEOUT = 5,     /* an in-kernel bounded spin gave up (device status word set)      */
+    KR_ERR_STATE = 6        /* call order violated (e.g. update before backward)               */
+};
+
+enum kr_flags {
+    KR_STORE_FW = 1u << 0, /* keep forward storage Phi (workspace.jl:128), slot n+1 = state after step n */
+    KR_NO_STORE_FW = 1u << 1
+};
+
+enum kr_functional { /* standard final-time functionals, weights 1 [QuantumControl.Functionals] */
+    KR_J_T_SM = 0,     /* 1 - |1/K sum tau|^2 ; chi_k = (sum tau)/K^2 * tgt_k */
+    KR_J_T_SS = 1,     /* 1 - 1/K sum |tau|^2 ; chi_k = tau_k/K * tgt_k       */
+    KR_J_T_RE = 2      /* 1 - Re(1/K sum tau) ; chi_k = tgt_k/(2K)            */
+};
+
+enum kr_which_storage { KR_STORAGE_FW = 0, KR_STORAGE_BW = 1 };
+
+typedef struct kr_config {
+    int32_t abi_version; /* = KR_ABI_VERSION */
+    int32_t N;           /* state-vector length (Hilbert or Liouville dimension)              */
+    int32_t NT;          /* number of time intervals = length(tlist)-1 (optimize.jl:255,282)   */
+    int32_t K;           /* number of trajectories LOCAL to this handle (optimize.jl:283)      */
+    int32_t L;           /* number of controls (optimize.jl:284); 0 is an error                */
+    int32_t G;           /* number of distinct generators (1 = shared by all trajectories)    */
+    const int32_t *traj_generator; /* [K] k -> g, or NULL when G == 1                          */
+    const double *tlist;           /* [NT+1]                                                   */
+    const double *H0;              /* [G][N*N] drift, column-major complex                     */
+    const double *Hc;              /* [G][L][N*N] control operators = dH/d eps_l (workspace.jl:74) */
+    const uint8_t *hc_present;     /* [G][L] 0 where the derivative is `nothing` (optimize.jl:344), or NULL */
+    uint32_t flags;                /* kr_flags                                                 */
+    double prop_tol;               /* truncation bound of the step propagator per step; <=0 -> 1e-16 */
+    int32_t device;                /* HIP device ordinal, -1 = current                         */
+    /* multi-GPU (one process per GPU; trajectories sharded, K above is the local count)      */
+    int32_t rank;                  /* 0 .. world-1 */
+    int32_t world;                 /* 1 = single GPU */
+    int32_t K_global;              /* total trajectories over all ranks (0 -> K)               */
+    int32_t reserved[8];
+} kr_config;
+
+typedef struct kr_handle kr_handle;
+
+/* Creation mirrors KrotovWrk(problem) (workspace.jl:65-200) for what lives on the device. */
+int kr_create(const kr_config *cfg, kr_handle **out);
+int kr_destroy(kr_handle *h);
+const char *kr_last_error(const kr_handle *h); /* h may be NULL: error of the last failed kr_create */
+int kr_abi_version(void);
+
+/* Use an existing HIP stream (e.g. torch's current stream); NULL = the handle's own stream. */
+int kr_set_stream(kr_handle *h, void *hip_stream);
+
+/* trajectories[k].initial_state (optimize.jl:323); targets only for the device functionals.  */
+int kr_set_initial_states(kr_handle *h, const double *psi0 /* [K][N] */);
+int kr_set_target_states(kr_handle *h, const double *tgt /* [K][N] */);
+
+/* a1: psi_k(t_{n+1}) = U_n(eps) psi_k(t_n); psiT_out may be NULL.                             */
+int kr_forward(kr_handle *h, const double *eps /* [L][NT] */, double *psiT_out /* [K][N] */);
+/* a3: X[NT] = chiT; X[n] = U_n(eps)^dagger X[n+1]; X stays on the device.                     */
+int kr_backward(kr_handle *h, const double *eps_guess, const double *chiT /* [K][N] */);
+/* a4-a7: needs a preceding kr_backward.  eps_new_out / g_a_int_out / psiT_out are outputs.     */
+int kr_update_forward(kr_handle *h, const double *eps_guess, const double *S /* [L][NT] */,
+                      const double *lambda /* [L] */, double *eps_new_out /* [L][NT] */,
+                      double *g_a_int_out /* [L] */, double *psiT_out /* [K][N] or NULL */);
+/* krotov_iteration given chi(T): backward + update.                                           */
+int kr_iteration(kr_handle *h, const double *eps_guess, const double *chiT, const double *S,
+                 const double *lambda, double *eps_new_out, double *g_a_int_out, double *psiT_out);
+
+/* Device-resident chain for the standard functionals: tau, J_T and chi(T) are
+ * computed on the device from the final states of the previous sweep.  eps_dev_in/out: DEVICE
+ * pointers [L][NT]; S/lambda host.  out_host (may be NULL) receives {J_T_before, g_a_int[0..L-1]}
+ * only when sync != 0.                                                                         */
+int kr_set_update_params(kr_handle *h, const double *S /* [L][NT] */, const double *lambda /* [L] */);
+int kr_forward_dev(kr_handle *h, const void *eps_dev);
+int kr_iteration_functional_dev(kr_handle *h, int functional, const void *eps_guess_dev,
+                                void *eps_new_dev);
+/* tau_k = <tgt_k|psi_k(T)> and J_T of the states left by the last forward/update sweep.       */
+int kr_final_states(kr_handle *h, double *psiT_out /* [K][N] */);
+int kr_taus(kr_handle *h, double *tau_out /* [K] complex */);
+int kr_g_a_int(kr_handle *h, double *g_a_int_out /* [L] */);
+int kr_synchronize(kr_handle *h);
+
+/* Callback inspection (workspace.jl:24; optimize.jl:258-262): state k at time index n (0..NT). */
+int kr_read_storage(kr_handle *h, int which, int k, int n, double *out /* [N] */);
+
+/* Introspection for bench / tests. info_out: {NP, n_workgroups, traj_per_wg, threads, taylor_order_bw_max,
+ * substeps_max, variant, reserved...} (16 ints). timings_ms: last {forward, backward, update} kernel
+ * durations measured with HIP events on the handle's stream (3 doubles; <0 = not run).          */
+int kr_get_info(kr_handle *h, int32_t *info_out /* [16] */);
+int kr_get_timings(kr_handle *h, double *timings_ms /* [3] */);
+int kr_enable_timing(kr_handle *h, int on);
+
+/* Multi-GPU mailbox wiring (in-kernel per-step exchange of the L partial sums).
+ * Each rank exports an IPC handle of its mailbox, the host side all-gathers them
+ * (torch.distributed), each rank then connects to all peers.                                   */
+int kr_ipc_handle_size(void);
+int kr_ipc_export(kr_handle *h, void *handle_out /* kr_ipc_handle_size() bytes */);
+int kr_ipc_connect(kr_handle *h, const void *all_handles /* [world][kr_ipc_handle_size()] */);
+#ifdef __cplusplus
+}
+#endif
+#endif /* KROTOV_HIP_H */

@@ -1,0 +1,599 @@
+// Device code of the Krotov sweeps for gfx950 (CDNA4).  Register-resident-generator variant,
+// state dimension padded to NP in {8,16,32,64}.
+//
+// Mapping (one 256-thread workgroup per CU, persistent over all N_T time steps):
+//   team  = JQ*NP threads (JQ = 4, or 8 for NP = 64 where the workgroup has 512 threads) that own ONE copy of the generator slices H0, H_1..H_L in registers:
+//           thread (i, jq) holds row i, columns [jq*JS, (jq+1)*JS), JS = NP/4, of every matrix;
+//   a workgroup has SG = 256/(4*NP) teams; each team propagates KT trajectories, so one
+//   workgroup carries KTILE = SG*KT trajectories and the generator is read from HBM/L2 ONCE per
+//   sweep, not once per step.
+//   A matvec y = H x reads the x slice from LDS (16-B reads, broadcast across the rows of a
+//   wave, padded so the four column segments fall on different banks), does 4*JS fp64 FMAs per
+//   thread in four independent chains, and sums the four column segments of a row inside the
+//   lane quad with DPP (no LDS, no wave-wide shuffle).
+//   The step propagator exp(-i H(eps_n) dt) is never formed: it is applied as a Horner-form
+//   Taylor polynomial of order m (chosen per step from ||H(eps_n)|| dt so that the truncation
+//   bound is below tol), with H(eps_n) = H0 + sum_l eps_l[n] H_l combined in registers.
+//
+// Reference semantics restated (paths under /root/reference):
+//   kr_sweep_known  : optimize.jl:247-265 (initial forward sweep) and :303-317 (backward sweep
+//                     through the adjoint generator, workspace.jl:69,149-161)
+//   kr_sweep_update : optimize.jl:321-370 -- per step: du_l = sum_k Im<chi_k|H_l|psi_k> (:339-349),
+//                     eps_new = eps + S/lambda du, g_a_int += S/lambda |du|^2 dt (:351-358), then
+//                     psi_k <- U_n(eps_new) psi_k (:360-368).
+#pragma once
+#include "kr_common.h"
+
+template <int NP, int LMAX, int KT>
+struct KrGeom {
+    static constexpr int JQ = (NP >= 64) ? 8 : 4;       // lanes that share one row
+    static constexpr int THREADS = (NP >= 64) ? 512 : 256;  // NP=64: 2 waves/SIMD so the slices fit 256 VGPRs
+    static constexpr int NW = THREADS / 64;
+    static constexpr int JS = NP / JQ;
+    static constexpr int RT = NP * JQ;
+    static constexpr int SG = THREADS / RT;
+    static constexpr int KTILE = SG * KT;
+    static constexpr int NPP = NP + JQ;  // one 16-B pad slot per column segment
+    static_assert(NP >= 8 && NP <= 64 && (NP & (NP - 1)) == 0, "NP in {8,16,32,64}");
+};
+
+// ---- lane-quad sum (lanes 4r..4r+3 hold the four column segments of row r) -----------------
+__device__ __forceinline__ double kr_dpp_quad_swap(double v, const int which) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (which == 1) {  // quad_perm:[1,0,3,2]
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    } else {  // quad_perm:[2,3,0,1]
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+    }
+    return __hiloint2double(hi, lo);
+}
+// sum over the JQ (4 or 8) consecutive lanes that share a row; every lane gets the sum
+template <int JQ>
+__device__ __forceinline__ double kr_row_sum(double v) {
+    v += kr_dpp_quad_swap(v, 1);
+    v += kr_dpp_quad_swap(v, 2);
+    if (JQ == 8) {  // row_half_mirror: lane j <-> 7-j inside each group of 8
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true);
+        v += __hiloint2double(hi, lo);
+    }
+    return v;
+}
+
+// wave-wide butterfly sum, fixed order (bitwise reproducible, identical in every lane)
+__device__ __forceinline__ double kr_wave_sum(double v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long kr_realtime() { return __builtin_amdgcn_s_memrealtime(); }
+
+typedef __attribute__((address_space(1))) unsigned long long kr_gu64;
+typedef __attribute__((address_space(1))) unsigned kr_gu32;
+
+// y_i = sum_j E_ij x_j for this thread's column segment; returns the quad-reduced row sum.
+template <int JS, int JQ>
+__device__ __forceinline__ void kr_row_dot(const double (&Er)[JS], const double (&Ei)[JS],
+                                           const double2 *__restrict__ xp, double &sr, double &si) {
+    double a = 0, b = 0, c = 0, d = 0;
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj) {
+        const double2 x = xp[jj];
+        a = fma(Er[jj], x.x, a);
+        b = fma(Ei[jj], x.y, b);
+        c = fma(Er[jj], x.y, c);
+        d = fma(Ei[jj], x.x, d);
+    }
+    sr = kr_row_sum<JQ>(a - b);
+    si = kr_row_sum<JQ>(c + d);
+}
+
+// =============================================================================================
+// Known-pulse sweep: forward (dir=+1) or backward through the adjoint generator (dir=-1).
+// No inter-workgroup communication: every workgroup runs its own trajectories to the end.
+// =============================================================================================
+template <int NP, int LMAX, int KT>
+__global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, KT>::THREADS / 256)) void kr_sweep_known(const KrSweepArgs a) {
+    using G = KrGeom<NP, LMAX, KT>;
+    constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, KTILE = G::KTILE, NPP = G::NPP;
+    __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];
+    __shared__ __attribute__((aligned(16))) double2 sy[2][KTILE][NPP];
+
+    const int tid = threadIdx.x, wg = blockIdx.x;
+    const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
+    const bool writer = (jq == 0), row_ok = (i < a.N);
+    const int pi_ = i + i / JS;          // padded position of element i
+    const int xoff = jq * (JS + 1);      // padded start of this thread's column segment
+    const int N = a.N, NT = a.NT, L = a.L;
+
+    double Hr[LMAX + 1][JS], Hi[LMAX + 1][JS];
+#pragma unroll
+    for (int m = 0; m <= LMAX; ++m) {
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) {
+            double2 h = make_double2(0.0, 0.0);
+            if (m <= L) h = a.Hpack[((size_t)m * JS + jj) * RT + tt];
+            Hr[m][jj] = h.x;
+            Hi[m][jj] = h.y;
+        }
+    }
+
+    double pr[KT], pim[KT];
+    size_t kbase[KT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+        const int k = wg * KTILE + q * SG + team;
+        kbase[q] = (size_t)k * N;
+        double2 v = make_double2(0.0, 0.0);
+        if (row_ok) v = a.init[kbase[q] + i];
+        pr[q] = v.x;
+        pim[q] = v.y;
+        if (writer) sx[0][q * SG + team][pi_] = v;
+        if (a.store && writer && row_ok) {
+            const int slot0 = (a.dir > 0) ? 0 : NT;
+            a.store[(size_t)slot0 * a.Kp * N + kbase[q] + i] = v;
+        }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = 0; step < NT; ++step) {
+        const int n = (a.dir > 0) ? step : (NT - 1 - step);
+        const double sdt = (a.dir > 0) ? a.dt[n] : -a.dt[n];
+        double e[LMAX];
+        double theta = a.nrm[0];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            e[l] = 0.0;
+            if (l < L) {
+                e[l] = a.eps[(size_t)l * NT + n];
+                theta += fabs(e[l]) * a.nrm[1 + l];
+            }
+        }
+        theta *= fabs(sdt);
+        int s, m;
+        kr_taylor_plan(theta, a.tol, s, m);
+
+        double Er[JS], Ei[JS];
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) {
+            double r = Hr[0][jj], im = Hi[0][jj];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l < L) {
+                    r = fma(e[l], Hr[1 + l][jj], r);
+                    im = fma(e[l], Hi[1 + l][jj], im);
+                }
+            }
+            Er[jj] = r;
+            Ei[jj] = im;
+        }
+
+        const double fs = sdt / (double)s;
+        for (int sub = 0; sub < s; ++sub) {
+            int w = 0;
+            for (int j = m; j >= 1; --j) {  // Horner: y <- psi + (-i fs / j) H y
+                const double f = fs / (double)j;
+#pragma unroll
+                for (int q = 0; q < KT; ++q) {
+                    const int tq = q * SG + team;
+                    const double2 *src = (j == m) ? &sx[cur][tq][xoff] : &sy[w ^ 1][tq][xoff];
+                    double sr, si;
+                    kr_row_dot<JS, JQ>(Er, Ei, src, sr, si);
+                    const double yr = fma(f, si, pr[q]);
+                    const double yi = fma(-f, sr, pim[q]);
+                    if (j > 1) {
+                        if (writer) sy[w][tq][pi_] = make_double2(yr, yi);
+                    } else {
+                        pr[q] = yr;
+                        pim[q] = yi;
+                        if (writer) sx[cur ^ 1][tq][pi_] = make_double2(yr, yi);
+                    }
+                }
+                __syncthreads();
+                w ^= 1;
+            }
+            cur ^= 1;
+        }
+
+        if (a.store && writer && row_ok) {
+            const int slot = (a.dir > 0) ? (n + 1) : n;
+#pragma unroll
+            for (int q = 0; q < KT; ++q)
+                a.store[(size_t)slot * a.Kp * N + kbase[q] + i] = make_double2(pr[q], pim[q]);
+        }
+    }
+    if (a.fin && writer && row_ok) {
+#pragma unroll
+        for (int q = 0; q < KT; ++q) a.fin[kbase[q] + i] = make_double2(pr[q], pim[q]);
+    }
+}
+
+// =============================================================================================
+// Per-step exchange of the L partial sums between the P workgroups of this GPU (and, for
+// world > 1, between GPUs through peer mailboxes over xGMI).  One hop, all-to-all: every
+// workgroup publishes 2L eight-byte granules {tag | half of a double} with agent-scope atomic
+// stores (write-through), wave 0 of every workgroup polls all P slots with agent-scope loads
+// and sums them in slot order, so every workgroup of every GPU obtains the bitwise identical
+// total.  Slots are double-buffered by step parity; tags increase monotonically over the life of
+// the handle, so nothing needs clearing between launches.  Spins are bounded.
+// Returns false when the exchange was aborted (status[0] set).
+// =============================================================================================
+template <int LMAX, int NW>
+__device__ __forceinline__ double kr_sum_waves(const double *sred, const int l) {
+    double v = sred[l];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += sred[w * LMAX + l];  // fixed order
+    return v;
+}
+
+template <int LMAX, int NW>
+__device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg,
+                                            const double (&part)[LMAX], double (&total)[LMAX],
+                                            double *sred /*[NW*LMAX]*/, double *stot /*[LMAX+1]*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = a.L, P = a.P;
+    const unsigned tag = a.epoch_base + (unsigned)n + 1u;
+    const int par = n & 1;
+
+    // 1. workgroup partial: wave sums, then the four waves in fixed order
+    double wsum[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) wsum[l] = (l < L) ? kr_wave_sum(part[l]) : 0.0;
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) sred[wave * LMAX + l] = wsum[l];
+    }
+    __syncthreads();
+
+    if (wave == 0) {
+        bool ok_all = true;
+        double tot[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
+        if (P == 1 && a.world == 1) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l)
+                tot[l] = kr_sum_waves<LMAX, NW>(sred, l);
+        } else {
+            // 2. publish this workgroup's partial
+            kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)par * P + wg) * (2 * LMAX));
+            if (lane < 2 * L) {
+                const int l = lane >> 1;
+                const double v = kr_sum_waves<LMAX, NW>(sred, l);
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+                __hip_atomic_store(slot + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // 3. gather all P slots (lane handles slots lane, lane+64, ...), bounded spin
+            const unsigned long long t0 = kr_realtime();
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
+                for (int q = lane; q < P; q += 64) {
+                    kr_gu64 *sq = (kr_gu64 *)(a.mail + ((size_t)par * P + q) * (2 * LMAX));
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        if (l < L) {
+                            const unsigned long long g0 = __hip_atomic_load(sq + 2 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long g1 = __hip_atomic_load(sq + 2 * l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && ((unsigned)(g0 >> 32) == tag) && ((unsigned)(g1 >> 32) == tag);
+                            const unsigned long long bits = (g1 << 32) | (g0 & 0xffffffffull);
+                            tot[l] += __longlong_as_double((long long)bits);
+                        }
+                    }
+                }
+                if (__all(ok)) break;
+                if ((++spins & 63u) == 0u) {
+                    const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (st != 0u || kr_realtime() - t0 > KR_SPIN_TIMEOUT_TICKS) {
+                        if (lane == 0 && st == 0u) {
+                            __hip_atomic_store((kr_gu32 *)a.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store((kr_gu32 *)a.status + 2, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store((kr_gu32 *)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        ok_all = false;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(tot[l]);
+
+            // 4. inter-GPU hop: workgroup 0 pushes the GPU total into every rank's xmail; every
+            //    workgroup polls its own GPU's xmail and sums the ranks in rank order.
+            if (a.world > 1 && ok_all) {
+                const int W = a.world;
+                if (wg == 0 && lane < 2 * L * W) {
+                    const int r = lane / (2 * L), g = lane % (2 * L), l = g >> 1;
+                    double v = 0.0;
+#pragma unroll
+                    for (int ll = 0; ll < LMAX; ++ll) if (ll == l) v = tot[ll];
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                    const unsigned half = (g & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+                    kr_gu64 *dst = (kr_gu64 *)(a.peer_xmail[r] + ((size_t)par * W + a.rank) * (2 * LMAX) + g);
+                    __hip_atomic_store(dst, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                const unsigned long long t1 = kr_realtime();
+                spins = 0;
+                double gt[LMAX];
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) gt[l] = 0.0;
+                    for (int r = 0; r < W; ++r) {  // every lane reads every rank: rank order, identical everywhere
+                        kr_gu64 *sq = (kr_gu64 *)(a.xmail + ((size_t)par * W + r) * (2 * LMAX));
+#pragma unroll
+                        for (int l = 0; l < LMAX; ++l) {
+                            if (l < L) {
+                                const unsigned long long g0 = __hip_atomic_load(sq + 2 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                const unsigned long long g1 = __hip_atomic_load(sq + 2 * l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                ok = ok && ((unsigned)(g0 >> 32) == tag) && ((unsigned)(g1 >> 32) == tag);
+                                const unsigned long long bits = (g1 << 32) | (g0 & 0xffffffffull);
+                                gt[l] += __longlong_as_double((long long)bits);
+                            }
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if ((++spins & 63u) == 0u) {
+                        const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (st != 0u || kr_realtime() - t1 > KR_SPIN_TIMEOUT_TICKS) {
+                            if (lane == 0 && st == 0u) {
+                                __hip_atomic_store((kr_gu32 *)a.status + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store((kr_gu32 *)a.status + 2, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store((kr_gu32 *)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            ok_all = false;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) tot[l] = gt[l];
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) stot[l] = tot[l];
+            stot[LMAX] = ok_all ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) total[l] = stot[l];
+    return stot[LMAX] != 0.0;
+}
+
+// =============================================================================================
+// Update sweep (optimize.jl:321-370): strictly sequential in n, one global sum per step.
+// =============================================================================================
+template <int NP, int LMAX, int KT>
+__global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, KT>::THREADS / 256)) void kr_sweep_update(const KrSweepArgs a) {
+    using G = KrGeom<NP, LMAX, KT>;
+    constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, KTILE = G::KTILE, NPP = G::NPP, NW = G::NW;
+    __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];
+    __shared__ __attribute__((aligned(16))) double2 sy[2][KTILE][NPP];
+    __shared__ double sred[NW * LMAX];
+    __shared__ double stot[LMAX + 1];
+
+    const int tid = threadIdx.x, wg = blockIdx.x;
+    const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
+    const bool writer = (jq == 0), row_ok = (i < a.N);
+    const int pi_ = i + i / JS;
+    const int xoff = jq * (JS + 1);
+    const int N = a.N, NT = a.NT, L = a.L;
+    const size_t slab = (size_t)a.Kp * N;
+
+    double Hr[LMAX + 1][JS], Hi[LMAX + 1][JS];
+#pragma unroll
+    for (int m = 0; m <= LMAX; ++m) {
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) {
+            double2 h = make_double2(0.0, 0.0);
+            if (m <= L) h = a.Hpack[((size_t)m * JS + jj) * RT + tt];
+            Hr[m][jj] = h.x;
+            Hi[m][jj] = h.y;
+        }
+    }
+
+    double pr[KT], pim[KT], cr[KT], ci[KT];
+    size_t kbase[KT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+        const int k = wg * KTILE + q * SG + team;
+        kbase[q] = (size_t)k * N;
+        double2 v = make_double2(0.0, 0.0), c = make_double2(0.0, 0.0);
+        if (row_ok) {
+            v = a.init[kbase[q] + i];
+            c = a.X[kbase[q] + i];  // chi_k(t_0)
+        }
+        pr[q] = v.x; pim[q] = v.y; cr[q] = c.x; ci[q] = c.y;
+        if (writer) sx[0][q * SG + team][pi_] = v;
+        if (a.store && writer && row_ok) a.store[kbase[q] + i] = v;
+    }
+    double gint[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) gint[l] = 0.0;
+    __syncthreads();
+
+    int cur = 0;
+    for (int n = 0; n < NT; ++n) {
+        const double dt = a.dt[n];
+        // ---- phase A: a_m = H_m psi (m = 0..L) and the partial sums Im<chi|H_l|psi> ----------
+        double a0r[KT], a0i[KT], alr[KT][LMAX], ali[KT][LMAX];
+        double part[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) part[l] = 0.0;
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+            const int tq = q * SG + team;
+            const double2 *src = &sx[cur][tq][xoff];
+            kr_row_dot<JS, JQ>(Hr[0], Hi[0], src, a0r[q], a0i[q]);
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                alr[q][l] = 0.0; ali[q][l] = 0.0;
+                if (l < L) {
+                    kr_row_dot<JS, JQ>(Hr[1 + l], Hi[1 + l], src, alr[q][l], ali[q][l]);
+                    // Im(conj(chi) * a) = chi_r a_i - chi_i a_r ; one lane per row contributes
+                    if (writer && ((a.present_mask >> l) & 1u)) part[l] += cr[q] * ali[q][l] - ci[q] * alr[q][l];
+                }
+            }
+        }
+        // prefetch chi(t_{n+1}) for the next step; it lands during the exchange / Taylor phase
+        if (n + 1 < NT && row_ok) {
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+                const double2 c = a.X[(size_t)(n + 1) * slab + kbase[q] + i];
+                cr[q] = c.x; ci[q] = c.y;
+            }
+        }
+
+        // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
+        double du[LMAX];
+        if (!kr_exchange<LMAX, NW>(a, n, wg, part, du, sred, stot)) return;
+
+        // ---- pulse update (optimize.jl:351-358), identical on every workgroup ---------------
+        double e[LMAX];
+        double theta = a.nrm[0];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            e[l] = 0.0;
+            if (l < L) {
+                const double alpha = __ddiv_rn(a.S[(size_t)l * NT + n], a.lambda[l]);
+                const double deps = __dmul_rn(alpha, du[l]);
+                e[l] = __dadd_rn(a.eps[(size_t)l * NT + n], deps);
+                const double ad = fabs(du[l]);
+                gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dt));
+                theta += fabs(e[l]) * a.nrm[1 + l];
+                if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = e[l];
+            }
+        }
+        theta *= fabs(dt);
+        int s, m;
+        kr_taylor_plan(theta, a.tol, s, m);
+
+        double Er[JS], Ei[JS];
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) {
+            double r = Hr[0][jj], im = Hi[0][jj];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l < L) {
+                    r = fma(e[l], Hr[1 + l][jj], r);
+                    im = fma(e[l], Hi[1 + l][jj], im);
+                }
+            }
+            Er[jj] = r;
+            Ei[jj] = im;
+        }
+
+        // ---- phase B: psi <- exp(-i H dt) psi.  The first application H psi = a0 + sum e_l a_l
+        //      is already known, so sub-step 0 costs m-1 matvecs:
+        //      psi' = psi + y1,  y_m = v,  y_{j-1} = v + (-i fs / j) H y_j,  v = -i fs (H psi)
+        const double fs = dt / (double)s;
+        {
+            double vr[KT], vi[KT];
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+                double wr = a0r[q], wi = a0i[q];
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    if (l < L) { wr = fma(e[l], alr[q][l], wr); wi = fma(e[l], ali[q][l], wi); }
+                }
+                vr[q] = fs * wi;   // -i (wr + i wi) = wi - i wr
+                vi[q] = -fs * wr;
+                if (m > 1 && writer) sy[0][q * SG + team][pi_] = make_double2(vr[q], vi[q]);
+            }
+            if (m > 1) __syncthreads();
+            int w = 1;
+            double yr[KT], yi[KT];
+#pragma unroll
+            for (int q = 0; q < KT; ++q) { yr[q] = vr[q]; yi[q] = vi[q]; }
+            for (int j = m; j >= 2; --j) {
+                const double f = fs / (double)j;
+#pragma unroll
+                for (int q = 0; q < KT; ++q) {
+                    const int tq = q * SG + team;
+                    double sr, si;
+                    kr_row_dot<JS, JQ>(Er, Ei, &sy[w ^ 1][tq][xoff], sr, si);
+                    yr[q] = fma(f, si, vr[q]);
+                    yi[q] = fma(-f, sr, vi[q]);
+                    if (j > 2 && writer) sy[w][tq][pi_] = make_double2(yr[q], yi[q]);
+                }
+                if (j > 2) __syncthreads();
+                w ^= 1;
+            }
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+                pr[q] += yr[q];
+                pim[q] += yi[q];
+                if (writer) sx[cur ^ 1][q * SG + team][pi_] = make_double2(pr[q], pim[q]);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        for (int sub = 1; sub < s; ++sub) {  // further sub-steps (only when ||H dt|| > KR_THETA_MAX)
+            int w = 0;
+            for (int j = m; j >= 1; --j) {
+                const double f = fs / (double)j;
+#pragma unroll
+                for (int q = 0; q < KT; ++q) {
+                    const int tq = q * SG + team;
+                    const double2 *src = (j == m) ? &sx[cur][tq][xoff] : &sy[w ^ 1][tq][xoff];
+                    double sr, si;
+                    kr_row_dot<JS, JQ>(Er, Ei, src, sr, si);
+                    const double y_r = fma(f, si, pr[q]);
+                    const double y_i = fma(-f, sr, pim[q]);
+                    if (j > 1) {
+                        if (writer) sy[w][tq][pi_] = make_double2(y_r, y_i);
+                    } else {
+                        pr[q] = y_r; pim[q] = y_i;
+                        if (writer) sx[cur ^ 1][tq][pi_] = make_double2(y_r, y_i);
+                    }
+                }
+                __syncthreads();
+                w ^= 1;
+            }
+            cur ^= 1;
+        }
+
+        if (a.store && writer && row_ok) {
+#pragma unroll
+            for (int q = 0; q < KT; ++q)
+                a.store[(size_t)(n + 1) * slab + kbase[q] + i] = make_double2(pr[q], pim[q]);
+        }
+    }
+    if (a.fin && writer && row_ok) {
+#pragma unroll
+        for (int q = 0; q < KT; ++q) a.fin[kbase[q] + i] = make_double2(pr[q], pim[q]);
+    }
+    if (wg == 0 && tid == 0) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
+    }
+}
+
+// ---- launcher table for one NP ---------------------------------------------------------------
+template <int NP>
+static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
+#define KR_CASE(LM, KTv)                                                                          \
+    if (lmax == LM && kt == KTv) {                                                                \
+        if (kind == 0) hipLaunchKernelGGL((kr_sweep_known<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        else hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a);          \
+        return hipGetLastError();                                                                 \
+    }
+    KR_CASE(2, 1) KR_CASE(2, 2) KR_CASE(2, 4)
+    KR_CASE(4, 1) KR_CASE(4, 2) KR_CASE(4, 4)
+#undef KR_CASE
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,702 @@
+// libkrotov_hip.so -- host side of the C ABI declared in include/krotov_hip.h.
+//
+// Owns: device memory (generator packs, pulses, storages X / Phi, states, mailboxes), the
+// launch plan (which kernel variant, how many workgroups, trajectories per workgroup), the
+// stream, and error reporting.  There is NO CPU fallback: without a HIP device kr_create fails
+// with KR_ERR_NO_DEVICE.
+//
+// Reference anchors (under /root/reference): what KrotovWrk builds per trajectory
+// (workspace.jl:128-161: three storages, fw and bw propagators from the trajectory and its
+// adjoint) is built here once per handle for all K trajectories.
+#include "../../include/krotov_hip.h"
+#include "kr_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+typedef std::complex<double> zc;
+
+static thread_local std::string g_create_error;
+
+struct kr_handle {
+    kr_config cfg{};
+    std::string err;
+    std::mutex mtx;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // plan
+    int NP = 0, LMAXv = 0, KT = 0, SG = 0, KTILE = 0, P = 0, Kp = 0, threads = 0, JQ = 4, JS = 0, RT = 0;
+    kr_launch_fn launch = nullptr;
+    bool store_fw = true;
+    double tol = 1e-16;
+    double nrm_fw[1 + KR_LMAX_CAP]{}, nrm_bw[1 + KR_LMAX_CAP]{};
+    unsigned present_mask = 0;
+    // device buffers
+    double2 *Hpack_fw = nullptr, *Hpack_bw = nullptr;
+    double *dt_d = nullptr, *eps_a = nullptr, *eps_b = nullptr, *S_d = nullptr, *lambda_d = nullptr, *gint_d = nullptr;
+    double2 *psi0_d = nullptr, *tgt_d = nullptr, *psiT_d = nullptr, *chiT_d = nullptr, *X_d = nullptr, *Phi_d = nullptr;
+    double2 *tau_d = nullptr, *tausum_d = nullptr;
+    unsigned long long *mail_d = nullptr, *xmail_d = nullptr;
+    unsigned long long *peer_xmail[8]{};
+    bool peers_connected = false;
+    unsigned *status_d = nullptr;
+    unsigned epoch_base = 0;
+    bool have_psi0 = false, have_tgt = false, have_X = false, have_final = false, have_params = false;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[6]{};
+    bool ev_used[3]{false, false, false};
+    // host staging
+    std::vector<double> stage;
+};
+
+static int fail(kr_handle *h, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((h), KR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- small host linear algebra ---------------------------------------------------------------
+// Upper bound (to a few %) of the spectral norm of a dense column-major matrix: power iteration on
+// A^H A with a safety factor, capped by sqrt(||A||_1 ||A||_inf) which is a rigorous bound.
+static double norm2_bound(int n, const zc *A) {
+    double n1 = 0, ninf = 0;
+    std::vector<double> rows(n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double s = 0;
+        for (int i = 0; i < n; ++i) { double v = std::abs(A[i + (size_t)j * n]); s += v; rows[i] += v; }
+        n1 = std::max(n1, s);
+    }
+    for (int i = 0; i < n; ++i) ninf = std::max(ninf, rows[i]);
+    const double cap = std::sqrt(n1 * ninf);
+    if (cap == 0.0) return 0.0;
+    std::vector<zc> x(n), y(n), z(n);
+    for (int i = 0; i < n; ++i) x[i] = zc(1.0 + 0.37 * std::sin(1.7 * i + 0.3), 0.21 * std::cos(2.3 * i));
+    double sigma = 0;
+    for (int it = 0; it < 200; ++it) {
+        double nx = 0;
+        for (int i = 0; i < n; ++i) nx += std::norm(x[i]);
+        nx = std::sqrt(nx);
+        if (nx == 0) break;
+        for (int i = 0; i < n; ++i) x[i] /= nx;
+        for (int i = 0; i < n; ++i) y[i] = 0;
+        for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) y[i] += A[i + (size_t)j * n] * x[j];
+        double ny = 0;
+        for (int i = 0; i < n; ++i) ny += std::norm(y[i]);
+        const double s_new = std::sqrt(ny);
+        for (int j = 0; j < n; ++j) {
+            zc acc = 0;
+            for (int i = 0; i < n; ++i) acc += std::conj(A[i + (size_t)j * n]) * y[i];
+            z[j] = acc;
+        }
+        x = z;
+        const bool done = (it > 8 && std::fabs(s_new - sigma) <= 1e-6 * s_new);
+        sigma = s_new;
+        if (done) break;
+    }
+    return std::min(cap, sigma * 1.05);
+}
+
+// Pack generator m (column-major N x N) into the thread-major slice layout of the kernels:
+// pack[(jj)*RT + i*JQ + jq] = M[i][jq*JS + jj]  (zero outside N).  adj: use M^dagger.
+static void pack_generator(int N, int NP, int JQ, const zc *M, bool adj, double2 *out) {
+    const int JS = NP / JQ, RT = NP * JQ;
+    for (int jj = 0; jj < JS; ++jj)
+        for (int i = 0; i < NP; ++i)
+            for (int jq = 0; jq < JQ; ++jq) {
+                const int j = jq * JS + jj;
+                zc v = 0;
+                if (i < N && j < N) v = adj ? std::conj(M[j + (size_t)i * N]) : M[i + (size_t)j * N];
+                out[(size_t)jj * RT + i * JQ + jq] = make_double2(v.real(), v.imag());
+            }
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+// ---- small device kernels for the standard functionals ---------------------
+// tau_k = <tgt_k|psi_k(T)>  (taus!, optimize.jl:381); one wave per trajectory.
+__global__ void kr_tau_kernel(const double2 *tgt, const double2 *psi, double2 *tau, int N, int K) {
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= K) return;
+    double sr = 0, si = 0;
+    for (int i = lane; i < N; i += 64) {
+        const double2 t = tgt[(size_t)k * N + i], p = psi[(size_t)k * N + i];
+        sr += t.x * p.x + t.y * p.y;  // conj(t) * p
+        si += t.x * p.y - t.y * p.x;
+    }
+    for (int o = 1; o < 64; o <<= 1) { sr += __shfl_xor(sr, o, 64); si += __shfl_xor(si, o, 64); }
+    if (lane == 0) tau[k] = make_double2(sr, si);
+}
+// serial, fixed-order sum of the K taus (K is small); single thread.
+__global__ void kr_tausum_kernel(const double2 *tau, double2 *out, int K) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double sr = 0, si = 0;
+        for (int k = 0; k < K; ++k) { sr += tau[k].x; si += tau[k].y; }
+        out[0] = make_double2(sr, si);
+    }
+}
+// chi_k(T) for J_T_sm / J_T_ss / J_T_re [QuantumControl.Functionals make_chi], weights 1.
+__global__ void kr_chi_kernel(int functional, const double2 *tgt, const double2 *tau, const double2 *tausum,
+                              double2 *chi, int N, int K, int Kp, double Kglobal) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Kp * N) return;
+    const int k = (int)(idx / N);
+    double2 c = make_double2(0.0, 0.0);
+    if (k < K) {
+        double fr, fi;
+        if (functional == KR_J_T_SM) { fr = tausum[0].x / (Kglobal * Kglobal); fi = tausum[0].y / (Kglobal * Kglobal); }
+        else if (functional == KR_J_T_SS) { fr = tau[k].x / Kglobal; fi = tau[k].y / Kglobal; }
+        else { fr = 1.0 / (2.0 * Kglobal); fi = 0.0; }
+        const double2 t = tgt[idx];
+        c = make_double2(fr * t.x - fi * t.y, fr * t.y + fi * t.x);
+    }
+    chi[idx] = c;
+}
+
+// ---- plan -------------------------------------------------------------------------------------
+static int make_plan(kr_handle *h) {
+    const kr_config &c = h->cfg;
+    if (c.N > 64) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 64: the streamed-generator kernel is not built yet", c.N);
+    if (c.L > KR_LMAX_CAP) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > %d controls not supported by the register-resident kernels", c.L, KR_LMAX_CAP);
+    int NP = 8;
+    while (NP < c.N) NP <<= 1;
+    h->NP = NP;
+    h->JQ = (NP >= 64) ? 8 : 4;
+    h->threads = (NP >= 64) ? 512 : 256;
+    h->JS = NP / h->JQ;
+    h->RT = NP * h->JQ;
+    h->SG = h->threads / h->RT;
+    h->LMAXv = (c.L <= 2) ? 2 : 4;
+    switch (NP) {
+        case 8: h->launch = kr_launch_np8; break;
+        case 16: h->launch = kr_launch_np16; break;
+        case 32: h->launch = kr_launch_np32; break;
+        default: h->launch = kr_launch_np64; break;
+    }
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+    int cus = prop.multiProcessorCount;
+    int maxwg = env_int("KROTOV_HIP_MAX_WG", cus);  // one persistent workgroup per CU
+    if (maxwg < 1) maxwg = 1;
+    int kt = env_int("KROTOV_HIP_KT", 0);
+    if (kt != 0 && kt != 1 && kt != 2 && kt != 4) return fail(h, KR_ERR_INVALID, "KROTOV_HIP_KT must be 1, 2 or 4");
+    if (kt == 0) {
+        kt = 1;
+        while (kt < 4 && (c.K + h->SG * kt - 1) / (h->SG * kt) > maxwg) kt <<= 1;
+    }
+    h->KT = kt;
+    h->KTILE = h->SG * kt;
+    h->P = (c.K + h->KTILE - 1) / h->KTILE;
+    if (h->P > maxwg)
+        return fail(h, KR_ERR_UNSUPPORTED, "K = %d trajectories need %d co-resident workgroups (> %d CUs) at NP = %d", c.K, h->P, maxwg, NP);
+    h->Kp = h->P * h->KTILE;
+    return KR_OK;
+}
+
+extern "C" int kr_abi_version(void) { return KR_ABI_VERSION; }
+
+extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static void free_all(kr_handle *h) {
+    void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->peers_connected)
+        for (int r = 0; r < h->cfg.world; ++r)
+            if (r != h->cfg.rank && h->peer_xmail[r]) (void)hipIpcCloseMemHandle(h->peer_xmail[r]);
+    if (h->xmail_d) (void)hipFree(h->xmail_d);
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+}
+
+extern "C" int kr_destroy(kr_handle *h) {
+    if (!h) return KR_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+    return KR_OK;
+}
+
+template <class T>
+static hipError_t dalloc(T **p, size_t count) {
+    return hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T));
+}
+
+extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
+    if (out) *out = nullptr;
+    if (!cfg || !out) return fail(nullptr, KR_ERR_INVALID, "kr_create: null argument");
+    if (cfg->abi_version != KR_ABI_VERSION) return fail(nullptr, KR_ERR_INVALID, "kr_create: abi_version %d != %d", cfg->abi_version, KR_ABI_VERSION);
+    if (cfg->L <= 0) return fail(nullptr, KR_ERR_INVALID, "no controls in trajectories: cannot optimize");  // workspace.jl:72
+    if (cfg->N <= 0 || cfg->NT <= 0 || cfg->K <= 0) return fail(nullptr, KR_ERR_INVALID, "kr_create: N, NT, K must be positive (got %d, %d, %d)", cfg->N, cfg->NT, cfg->K);
+    if (!cfg->tlist || !cfg->H0 || !cfg->Hc) return fail(nullptr, KR_ERR_INVALID, "kr_create: tlist, H0, Hc are required");
+    if (cfg->G != 1 || cfg->traj_generator) return fail(nullptr, KR_ERR_UNSUPPORTED, "kr_create: per-trajectory generators (G = %d) are not built yet; G must be 1", cfg->G);
+    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world || cfg->world > 8) return fail(nullptr, KR_ERR_INVALID, "kr_create: bad rank/world %d/%d", cfg->rank, cfg->world);
+    for (int n = 0; n < cfg->NT; ++n)
+        if (!(cfg->tlist[n + 1] > cfg->tlist[n])) return fail(nullptr, KR_ERR_INVALID, "kr_create: tlist must be strictly increasing (index %d)", n);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, KR_ERR_NO_DEVICE, "no HIP device available (%s); libkrotov_hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) return fail(nullptr, KR_ERR_INVALID, "kr_create: device %d out of range (%d devices)", dev, ndev);
+
+    kr_handle *h = new kr_handle();
+    h->cfg = *cfg;
+    h->cfg.traj_generator = nullptr; h->cfg.tlist = nullptr; h->cfg.H0 = nullptr; h->cfg.Hc = nullptr; h->cfg.hc_present = nullptr;
+    if (h->cfg.K_global <= 0) h->cfg.K_global = cfg->K;
+    h->device = dev;
+    h->store_fw = !(cfg->flags & KR_NO_STORE_FW);
+    h->tol = (cfg->prop_tol > 0) ? cfg->prop_tol : 1e-16;
+    int rc = KR_OK;
+    auto bail = [&](int code) { g_create_error = h->err; (void)hipSetDevice(dev); free_all(h); delete h; return code; };
+#define CHK(call) do { hipError_t e2_ = (call); if (e2_ != hipSuccess) { fail(h, KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2_)); return bail(KR_ERR_HIP); } } while (0)
+    CHK(hipSetDevice(dev));
+    rc = make_plan(h);
+    if (rc != KR_OK) return bail(rc);
+    CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    for (auto &ev : h->ev) CHK(hipEventCreate(&ev));
+
+    const int N = cfg->N, NT = cfg->NT, L = cfg->L, NP = h->NP;
+    const size_t nn = (size_t)N * N;
+    // norms and packs
+    const zc *H0 = (const zc *)cfg->H0, *Hc = (const zc *)cfg->Hc;
+    h->present_mask = 0;
+    h->nrm_fw[0] = h->nrm_bw[0] = norm2_bound(N, H0);
+    for (int l = 0; l < L; ++l) {
+        const bool present = !cfg->hc_present || cfg->hc_present[l];
+        if (present) h->present_mask |= 1u << l;
+        h->nrm_fw[1 + l] = h->nrm_bw[1 + l] = norm2_bound(N, Hc + (size_t)l * nn);
+    }
+    const size_t pack_elems = (size_t)(1 + L) * h->JS * h->RT;
+    std::vector<double2> pack(pack_elems);
+    CHK(dalloc(&h->Hpack_fw, pack_elems));
+    CHK(dalloc(&h->Hpack_bw, pack_elems));
+    for (int adj = 0; adj < 2; ++adj) {
+        for (int m = 0; m <= L; ++m)
+            pack_generator(N, NP, h->JQ, m == 0 ? H0 : Hc + (size_t)(m - 1) * nn, adj != 0, pack.data() + (size_t)m * h->JS * h->RT);
+        CHK(hipMemcpy(adj ? h->Hpack_bw : h->Hpack_fw, pack.data(), pack_elems * sizeof(double2), hipMemcpyHostToDevice));
+    }
+    std::vector<double> dt(NT);
+    for (int n = 0; n < NT; ++n) dt[n] = cfg->tlist[n + 1] - cfg->tlist[n];
+    CHK(dalloc(&h->dt_d, NT));
+    CHK(hipMemcpy(h->dt_d, dt.data(), sizeof(double) * NT, hipMemcpyHostToDevice));
+    CHK(dalloc(&h->eps_a, (size_t)L * NT));
+    CHK(dalloc(&h->eps_b, (size_t)L * NT));
+    CHK(dalloc(&h->S_d, (size_t)L * NT));
+    CHK(dalloc(&h->lambda_d, L));
+    CHK(dalloc(&h->gint_d, KR_LMAX_CAP));
+    const size_t slab = (size_t)h->Kp * N;
+    CHK(dalloc(&h->psi0_d, slab));
+    CHK(dalloc(&h->tgt_d, slab));
+    CHK(dalloc(&h->psiT_d, slab));
+    CHK(dalloc(&h->chiT_d, slab));
+    CHK(dalloc(&h->X_d, slab * (NT + 1)));
+    if (h->store_fw) CHK(dalloc(&h->Phi_d, slab * (NT + 1)));
+    CHK(dalloc(&h->tau_d, h->Kp));
+    CHK(dalloc(&h->tausum_d, 1));
+    CHK(hipMemset(h->psi0_d, 0, slab * sizeof(double2)));
+    CHK(hipMemset(h->tgt_d, 0, slab * sizeof(double2)));
+    CHK(hipMemset(h->psiT_d, 0, slab * sizeof(double2)));
+    CHK(hipMemset(h->chiT_d, 0, slab * sizeof(double2)));
+    CHK(hipMemset(h->gint_d, 0, KR_LMAX_CAP * sizeof(double)));
+    const size_t mail_words = (size_t)2 * h->P * 2 * KR_LMAX_CAP;
+    CHK(dalloc(&h->mail_d, mail_words));
+    CHK(hipMemset(h->mail_d, 0, mail_words * sizeof(unsigned long long)));
+    CHK(dalloc(&h->status_d, KR_STATUS_WORDS));
+    CHK(hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
+    if (cfg->world > 1) {
+        // inter-GPU mailbox: written by peers over xGMI, polled by this GPU's kernels -> uncached/fine-grained
+        const size_t xwords = (size_t)2 * 8 * 2 * KR_LMAX_CAP;
+        CHK(hipExtMallocWithFlags((void **)&h->xmail_d, xwords * sizeof(unsigned long long), hipDeviceMallocUncached));
+        CHK(hipMemset(h->xmail_d, 0, xwords * sizeof(unsigned long long)));
+        h->peer_xmail[cfg->rank] = h->xmail_d;
+    }
+    CHK(hipDeviceSynchronize());
+#undef CHK
+    *out = h;
+    return KR_OK;
+}
+
+extern "C" int kr_set_stream(kr_handle *h, void *hip_stream) {
+    if (!h) return KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return KR_OK;
+}
+
+extern "C" int kr_enable_timing(kr_handle *h, int on) {
+    if (!h) return KR_ERR_INVALID;
+    h->timing = on != 0;
+    return KR_OK;
+}
+
+extern "C" int kr_get_timings(kr_handle *h, double *t) {
+    if (!h || !t) return KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 3; ++i) {
+        t[i] = -1.0;
+        if (h->ev_used[i]) {
+            float ms = 0;
+            HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+            t[i] = ms;
+        }
+    }
+    return KR_OK;
+}
+
+extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
+    if (!h || !info) return KR_ERR_INVALID;
+    memset(info, 0, 16 * sizeof(int32_t));
+    info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
+    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ;
+    // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
+    return KR_OK;
+}
+
+// copy [K][N] host states into the zero-padded [Kp][N] device buffer
+static int upload_states(kr_handle *h, double2 *dst, const double *src) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)h->cfg.K * h->cfg.N * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+    return KR_OK;
+}
+
+extern "C" int kr_set_initial_states(kr_handle *h, const double *psi0) {
+    if (!h || !psi0) return h ? fail(h, KR_ERR_INVALID, "kr_set_initial_states: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = upload_states(h, h->psi0_d, psi0);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_psi0 = true;
+    return KR_OK;
+}
+
+extern "C" int kr_set_target_states(kr_handle *h, const double *tgt) {
+    if (!h || !tgt) return h ? fail(h, KR_ERR_INVALID, "kr_set_target_states: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = upload_states(h, h->tgt_d, tgt);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_tgt = true;
+    return KR_OK;
+}
+
+static void base_args(kr_handle *h, KrSweepArgs &a) {
+    memset(&a, 0, sizeof a);
+    a.dt = h->dt_d;
+    a.N = h->cfg.N; a.NT = h->cfg.NT; a.Kp = h->Kp; a.L = h->cfg.L;
+    a.P = h->P; a.rank = h->cfg.rank; a.world = h->cfg.world;
+    a.tol = h->tol;
+    a.present_mask = h->present_mask;
+    a.status = h->status_d;
+    a.mail = h->mail_d;
+    a.xmail = h->xmail_d;
+    for (int r = 0; r < 8; ++r) a.peer_xmail[r] = h->peer_xmail[r];
+}
+
+static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool backward, const double2 *init, double2 *store, double2 *fin) {
+    KrSweepArgs a;
+    base_args(h, a);
+    a.Hpack = backward ? h->Hpack_bw : h->Hpack_fw;
+    memcpy(a.nrm, backward ? h->nrm_bw : h->nrm_fw, sizeof a.nrm);
+    a.eps = eps_dev;
+    a.init = init; a.store = store; a.fin = fin;
+    a.dir = backward ? -1 : +1;
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2 * which_ev], h->stream));
+    HIPCHK(h, h->launch(h->LMAXv, h->KT, 0, h->P, h->stream, &a));
+    if (h->timing) { HIPCHK(h, hipEventRecord(h->ev[2 * which_ev + 1], h->stream)); h->ev_used[which_ev] = true; }
+    return KR_OK;
+}
+
+static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_new_dev) {
+    if (h->cfg.world > 1 && !h->peers_connected)
+        return fail(h, KR_ERR_STATE, "world = %d but kr_ipc_connect has not been called", h->cfg.world);
+    KrSweepArgs a;
+    base_args(h, a);
+    a.Hpack = h->Hpack_fw;
+    memcpy(a.nrm, h->nrm_fw, sizeof a.nrm);
+    a.eps = eps_guess_dev;
+    a.init = h->psi0_d; a.store = h->store_fw ? h->Phi_d : nullptr; a.fin = h->psiT_d;
+    a.X = h->X_d; a.S = h->S_d; a.lambda = h->lambda_d; a.eps_new = eps_new_dev; a.g_a_int = h->gint_d;
+    a.dir = +1;
+    a.epoch_base = h->epoch_base;
+    h->epoch_base += (unsigned)h->cfg.NT + 2u;
+    if (h->epoch_base > 0xfff00000u) h->epoch_base = 0;  // (tags restart; mailboxes hold older, larger tags only transiently)
+    HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+    HIPCHK(h, h->launch(h->LMAXv, h->KT, 1, h->P, h->stream, &a));
+    if (h->timing) { HIPCHK(h, hipEventRecord(h->ev[5], h->stream)); h->ev_used[2] = true; }
+    return KR_OK;
+}
+
+static int check_status(kr_handle *h) {
+    unsigned st[KR_STATUS_WORDS] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(st, h->status_d, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (st[0] != 0)
+        return fail(h, KR_ERR_TIMEOUT, "update sweep aborted: bounded spin of the %s exchange gave up at step %u", st[1] == 2 ? "inter-GPU" : "inter-workgroup", st[2]);
+    return KR_OK;
+}
+
+static int download_states(kr_handle *h, double *dst, const double2 *src) {
+    if (!dst) return KR_OK;
+    HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)h->cfg.K * h->cfg.N * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    return KR_OK;
+}
+
+extern "C" int kr_forward(kr_handle *h, const double *eps, double *psiT_out) {
+    if (!h || !eps) return h ? fail(h, KR_ERR_INVALID, "kr_forward: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    if (!h->have_psi0) return fail(h, KR_ERR_STATE, "kr_forward: initial states not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t pb = (size_t)h->cfg.L * h->cfg.NT * sizeof(double);
+    HIPCHK(h, hipMemcpyAsync(h->eps_a, eps, pb, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_known(h, 0, h->eps_a, false, h->psi0_d, h->store_fw ? h->Phi_d : nullptr, h->psiT_d);
+    if (rc) return rc;
+    rc = download_states(h, psiT_out, h->psiT_d);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_final = true;
+    return KR_OK;
+}
+
+extern "C" int kr_backward(kr_handle *h, const double *eps_guess, const double *chiT) {
+    if (!h || !eps_guess || !chiT) return h ? fail(h, KR_ERR_INVALID, "kr_backward: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t pb = (size_t)h->cfg.L * h->cfg.NT * sizeof(double);
+    HIPCHK(h, hipMemcpyAsync(h->eps_a, eps_guess, pb, hipMemcpyHostToDevice, h->stream));
+    int rc = upload_states(h, h->chiT_d, chiT);
+    if (rc) return rc;
+    rc = launch_known(h, 1, h->eps_a, true, h->chiT_d, h->X_d, nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_X = true;
+    return KR_OK;
+}
+
+static int set_params_locked(kr_handle *h, const double *S, const double *lambda) {
+    for (int l = 0; l < h->cfg.L; ++l)
+        if (!(lambda[l] != 0.0)) return fail(h, KR_ERR_INVALID, "lambda[%d] must be non-zero", l);
+    HIPCHK(h, hipMemcpyAsync(h->S_d, S, (size_t)h->cfg.L * h->cfg.NT * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->lambda_d, lambda, h->cfg.L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->have_params = true;
+    return KR_OK;
+}
+
+extern "C" int kr_set_update_params(kr_handle *h, const double *S, const double *lambda) {
+    if (!h || !S || !lambda) return h ? fail(h, KR_ERR_INVALID, "kr_set_update_params: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = set_params_locked(h, S, lambda);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KR_OK;
+}
+
+static int update_forward_locked(kr_handle *h, const double *eps_guess, const double *S, const double *lambda,
+                                 double *eps_new_out, double *g_a_int_out, double *psiT_out) {
+    if (!h->have_psi0) return fail(h, KR_ERR_STATE, "update sweep: initial states not set");
+    if (!h->have_X) return fail(h, KR_ERR_STATE, "update sweep: no backward sweep has been run");
+    const size_t pb = (size_t)h->cfg.L * h->cfg.NT * sizeof(double);
+    HIPCHK(h, hipMemcpyAsync(h->eps_a, eps_guess, pb, hipMemcpyHostToDevice, h->stream));
+    // eps_new starts as a copy of the guess (optimize.jl: pulses1 = copy(pulses0), workspace.jl:125)
+    HIPCHK(h, hipMemcpyAsync(h->eps_b, h->eps_a, pb, hipMemcpyDeviceToDevice, h->stream));
+    int rc = set_params_locked(h, S, lambda);
+    if (rc) return rc;
+    rc = launch_update(h, h->eps_a, h->eps_b);
+    if (rc) return rc;
+    rc = check_status(h);
+    if (rc) return rc;
+    if (eps_new_out) HIPCHK(h, hipMemcpyAsync(eps_new_out, h->eps_b, pb, hipMemcpyDeviceToHost, h->stream));
+    if (g_a_int_out) HIPCHK(h, hipMemcpyAsync(g_a_int_out, h->gint_d, h->cfg.L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    rc = download_states(h, psiT_out, h->psiT_d);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_final = true;
+    return KR_OK;
+}
+
+extern "C" int kr_update_forward(kr_handle *h, const double *eps_guess, const double *S, const double *lambda,
+                                 double *eps_new_out, double *g_a_int_out, double *psiT_out) {
+    if (!h || !eps_guess || !S || !lambda) return h ? fail(h, KR_ERR_INVALID, "kr_update_forward: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    return update_forward_locked(h, eps_guess, S, lambda, eps_new_out, g_a_int_out, psiT_out);
+}
+
+extern "C" int kr_iteration(kr_handle *h, const double *eps_guess, const double *chiT, const double *S,
+                            const double *lambda, double *eps_new_out, double *g_a_int_out, double *psiT_out) {
+    if (!h || !eps_guess || !chiT || !S || !lambda) return h ? fail(h, KR_ERR_INVALID, "kr_iteration: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t pb = (size_t)h->cfg.L * h->cfg.NT * sizeof(double);
+    HIPCHK(h, hipMemcpyAsync(h->eps_a, eps_guess, pb, hipMemcpyHostToDevice, h->stream));
+    int rc = upload_states(h, h->chiT_d, chiT);
+    if (rc) return rc;
+    rc = launch_known(h, 1, h->eps_a, true, h->chiT_d, h->X_d, nullptr);
+    if (rc) return rc;
+    h->have_X = true;
+    return update_forward_locked(h, eps_guess, S, lambda, eps_new_out, g_a_int_out, psiT_out);
+}
+
+// ---- device-resident chain ---------------------------------------------------------------------
+extern "C" int kr_forward_dev(kr_handle *h, const void *eps_dev) {
+    if (!h || !eps_dev) return h ? fail(h, KR_ERR_INVALID, "kr_forward_dev: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    if (!h->have_psi0) return fail(h, KR_ERR_STATE, "kr_forward_dev: initial states not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = launch_known(h, 0, (const double *)eps_dev, false, h->psi0_d, h->store_fw ? h->Phi_d : nullptr, h->psiT_d);
+    if (rc) return rc;
+    h->have_final = true;
+    return KR_OK;
+}
+
+static int launch_tau(kr_handle *h) {
+    const int K = h->cfg.K, N = h->cfg.N;
+    hipLaunchKernelGGL(kr_tau_kernel, dim3((K + 3) / 4), dim3(256), 0, h->stream, h->tgt_d, h->psiT_d, h->tau_d, N, K);
+    HIPCHK(h, hipGetLastError());
+    return KR_OK;
+}
+
+extern "C" int kr_iteration_functional_dev(kr_handle *h, int functional, const void *eps_guess_dev, void *eps_new_dev) {
+    if (!h || !eps_guess_dev || !eps_new_dev) return h ? fail(h, KR_ERR_INVALID, "kr_iteration_functional_dev: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    if (functional < KR_J_T_SM || functional > KR_J_T_RE) return fail(h, KR_ERR_INVALID, "unknown functional %d", functional);
+    if (!h->have_psi0 || !h->have_tgt) return fail(h, KR_ERR_STATE, "device chain: initial and target states must be set");
+    if (!h->have_final) return fail(h, KR_ERR_STATE, "device chain: no forward sweep has produced final states yet");
+    if (!h->have_params) return fail(h, KR_ERR_STATE, "device chain: kr_set_update_params has not been called");
+    if (functional == KR_J_T_SM && h->cfg.world > 1)
+        return fail(h, KR_ERR_UNSUPPORTED, "J_T_sm couples trajectories across ranks; use the host chi path for world > 1");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int K = h->cfg.K, N = h->cfg.N;
+    int rc = launch_tau(h);
+    if (rc) return rc;
+    if (functional == KR_J_T_SM) {
+        hipLaunchKernelGGL(kr_tausum_kernel, dim3(1), dim3(64), 0, h->stream, h->tau_d, h->tausum_d, K);
+        HIPCHK(h, hipGetLastError());
+    }
+    const size_t tot = (size_t)h->Kp * N;
+    hipLaunchKernelGGL(kr_chi_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, functional, h->tgt_d,
+                       h->tau_d, h->tausum_d, h->chiT_d, N, K, h->Kp, (double)h->cfg.K_global);
+    HIPCHK(h, hipGetLastError());
+    rc = launch_known(h, 1, (const double *)eps_guess_dev, true, h->chiT_d, h->X_d, nullptr);
+    if (rc) return rc;
+    h->have_X = true;
+    const size_t pb = (size_t)h->cfg.L * h->cfg.NT * sizeof(double);
+    HIPCHK(h, hipMemcpyAsync(eps_new_dev, eps_guess_dev, pb, hipMemcpyDeviceToDevice, h->stream));
+    return launch_update(h, (const double *)eps_guess_dev, (double *)eps_new_dev);
+}
+
+extern "C" int kr_synchronize(kr_handle *h) {
+    if (!h) return KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    return check_status(h);
+}
+
+extern "C" int kr_final_states(kr_handle *h, double *psiT_out) {
+    if (!h || !psiT_out) return h ? fail(h, KR_ERR_INVALID, "kr_final_states: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    if (!h->have_final) return fail(h, KR_ERR_STATE, "kr_final_states: no sweep has run");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = download_states(h, psiT_out, h->psiT_d);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KR_OK;
+}
+
+extern "C" int kr_taus(kr_handle *h, double *tau_out) {
+    if (!h || !tau_out) return h ? fail(h, KR_ERR_INVALID, "kr_taus: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    if (!h->have_final || !h->have_tgt) return fail(h, KR_ERR_STATE, "kr_taus: needs target states and a finished sweep");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = launch_tau(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(tau_out, h->tau_d, (size_t)h->cfg.K * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KR_OK;
+}
+
+extern "C" int kr_g_a_int(kr_handle *h, double *out) {
+    if (!h || !out) return h ? fail(h, KR_ERR_INVALID, "kr_g_a_int: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out, h->gint_d, h->cfg.L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KR_OK;
+}
+
+extern "C" int kr_read_storage(kr_handle *h, int which, int k, int n, double *out) {
+    if (!h || !out) return h ? fail(h, KR_ERR_INVALID, "kr_read_storage: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    if (k < 0 || k >= h->cfg.K || n < 0 || n > h->cfg.NT) return fail(h, KR_ERR_INVALID, "kr_read_storage: index (k=%d, n=%d) out of range", k, n);
+    const double2 *base = nullptr;
+    if (which == KR_STORAGE_BW) { if (!h->have_X) return fail(h, KR_ERR_STATE, "backward storage is empty"); base = h->X_d; }
+    else if (which == KR_STORAGE_FW) { if (!h->store_fw) return fail(h, KR_ERR_STATE, "forward storage disabled (KR_NO_STORE_FW)"); if (!h->have_final) return fail(h, KR_ERR_STATE, "forward storage is empty"); base = h->Phi_d; }
+    else return fail(h, KR_ERR_INVALID, "kr_read_storage: which = %d", which);
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t off = ((size_t)n * h->Kp + k) * h->cfg.N;
+    HIPCHK(h, hipMemcpyAsync(out, base + off, (size_t)h->cfg.N * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KR_OK;
+}
+
+// ---- multi-GPU mailbox wiring --------------------------------------------------------------------
+extern "C" int kr_ipc_handle_size(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+extern "C" int kr_ipc_export(kr_handle *h, void *handle_out) {
+    if (!h || !handle_out) return h ? fail(h, KR_ERR_INVALID, "kr_ipc_export: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    if (h->cfg.world <= 1) return fail(h, KR_ERR_STATE, "kr_ipc_export: world = 1");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipIpcMemHandle_t mh;
+    HIPCHK(h, hipIpcGetMemHandle(&mh, h->xmail_d));
+    memcpy(handle_out, &mh, sizeof mh);
+    return KR_OK;
+}
+
+extern "C" int kr_ipc_connect(kr_handle *h, const void *all_handles) {
+    if (!h || !all_handles) return h ? fail(h, KR_ERR_INVALID, "kr_ipc_connect: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    if (h->cfg.world <= 1) return fail(h, KR_ERR_STATE, "kr_ipc_connect: world = 1");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int r = 0; r < h->cfg.world; ++r) {
+        if (r == h->cfg.rank) continue;
+        hipIpcMemHandle_t mh;
+        memcpy(&mh, (const char *)all_handles + (size_t)r * sizeof mh, sizeof mh);
+        void *p = nullptr;
+        HIPCHK(h, hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess));
+        h->peer_xmail[r] = (unsigned long long *)p;
+    }
+    h->peers_connected = true;
+    return KR_OK;
+}

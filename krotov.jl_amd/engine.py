@@ -1,0 +1,197 @@
+"""HipEngine: the device-resident replacement of what KrotovWrk holds per trajectory
+(/root/reference/src/workspace.jl:128-161: fw/bw propagators and the three storages) plus the
+two hot functions that drive them (/root/reference/src/optimize.jl:247-265, 279-371).
+
+Array conventions on the Python side: operators (N, N) / (L, N, N) complex128 in NumPy C order,
+states (K, N) complex128, pulses (L, NT) float64.  Everything is handed to libkrotov_hip.so
+through the C ABI of include/krotov_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+
+class HipEngine:
+    def __init__(self, H0, Hc, tlist, K, *, hc_present=None, store_fw=True, prop_tol=0.0, device=-1,
+                 rank=0, world=1, K_global=0):
+        lib = capi.load()
+        self._lib = lib
+        self._h = C.c_void_p()
+        H0 = np.asarray(H0, np.complex128)
+        Hc = np.asarray(Hc, np.complex128)
+        if Hc.ndim == 2:
+            Hc = Hc[None]
+        tl = np.ascontiguousarray(tlist, np.float64)
+        self.N = int(H0.shape[0])
+        self.L = int(Hc.shape[0]) if Hc.size else 0
+        self.NT = len(tl) - 1
+        self.K = int(K)
+        self.rank, self.world = rank, world
+        H0c, Hcc = capi.colmajor(H0), capi.colmajor(Hc)
+        pres = None if hc_present is None else np.ascontiguousarray(hc_present, np.uint8)
+        cfg = capi.KrConfig()
+        cfg.abi_version = capi.KR_ABI_VERSION
+        cfg.N, cfg.NT, cfg.K, cfg.L, cfg.G = self.N, self.NT, self.K, self.L, 1
+        cfg.traj_generator = None
+        cfg.tlist, cfg.H0, cfg.Hc = capi.ptr(tl), capi.ptr(H0c), capi.ptr(Hcc)
+        cfg.hc_present = capi.ptr(pres)
+        cfg.flags = capi.KR_STORE_FW if store_fw else capi.KR_NO_STORE_FW
+        cfg.prop_tol = float(prop_tol)
+        cfg.device = device
+        cfg.rank, cfg.world, cfg.K_global = rank, world, K_global
+        rc = lib.kr_create(C.byref(cfg), C.byref(self._h))
+        if rc != capi.KR_OK:
+            msg = lib.kr_last_error(None)
+            self._h = C.c_void_p()
+            raise capi.KrotovHipError(rc, msg.decode() if msg else "?")
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _chk(self, rc):
+        capi.check(self._lib, self._h, rc)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.kr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _states(self, a, name):
+        a = np.ascontiguousarray(a, np.complex128)
+        if a.shape != (self.K, self.N):
+            raise ValueError("%s must have shape (K=%d, N=%d), got %r" % (name, self.K, self.N, a.shape))
+        return a
+
+    def _pulses(self, a, name):
+        a = np.ascontiguousarray(a, np.float64)
+        if a.shape != (self.L, self.NT):
+            raise ValueError("%s must have shape (L=%d, NT=%d), got %r" % (name, self.L, self.NT, a.shape))
+        return a
+
+    # -- ABI ----------------------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        self._chk(self._lib.kr_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def set_initial_states(self, psi0):
+        a = self._states(psi0, "psi0")
+        self._chk(self._lib.kr_set_initial_states(self._h, capi.ptr(a)))
+
+    def set_target_states(self, tgt):
+        a = self._states(tgt, "targets")
+        self._chk(self._lib.kr_set_target_states(self._h, capi.ptr(a)))
+
+    def forward(self, eps):
+        e = self._pulses(eps, "eps")
+        out = np.empty((self.K, self.N), np.complex128)
+        self._chk(self._lib.kr_forward(self._h, capi.ptr(e), capi.ptr(out)))
+        return out
+
+    def backward(self, eps_guess, chiT):
+        e = self._pulses(eps_guess, "eps_guess")
+        c = self._states(chiT, "chiT")
+        self._chk(self._lib.kr_backward(self._h, capi.ptr(e), capi.ptr(c)))
+
+    def update_forward(self, eps_guess, S, lam):
+        e = self._pulses(eps_guess, "eps_guess")
+        Sc = self._pulses(S, "S")
+        lc = np.ascontiguousarray(lam, np.float64)
+        eps_new = np.empty((self.L, self.NT))
+        ga = np.empty(self.L)
+        psiT = np.empty((self.K, self.N), np.complex128)
+        self._chk(self._lib.kr_update_forward(self._h, capi.ptr(e), capi.ptr(Sc), capi.ptr(lc), capi.ptr(eps_new),
+                                              capi.ptr(ga), capi.ptr(psiT)))
+        return eps_new, ga, psiT
+
+    def iteration(self, eps_guess, chiT, S, lam):
+        e = self._pulses(eps_guess, "eps_guess")
+        c = self._states(chiT, "chiT")
+        Sc = self._pulses(S, "S")
+        lc = np.ascontiguousarray(lam, np.float64)
+        eps_new = np.empty((self.L, self.NT))
+        ga = np.empty(self.L)
+        psiT = np.empty((self.K, self.N), np.complex128)
+        self._chk(self._lib.kr_iteration(self._h, capi.ptr(e), capi.ptr(c), capi.ptr(Sc), capi.ptr(lc),
+                                         capi.ptr(eps_new), capi.ptr(ga), capi.ptr(psiT)))
+        return eps_new, ga, psiT
+
+    def read_storage(self, which, k, n):
+        out = np.empty(self.N, np.complex128)
+        w = capi.KR_STORAGE_BW if which in ("bw", capi.KR_STORAGE_BW) else capi.KR_STORAGE_FW
+        self._chk(self._lib.kr_read_storage(self._h, w, int(k), int(n), capi.ptr(out)))
+        return out
+
+    def storage(self, which):
+        """Whole storage as (NT+1, K, N) -- test helper built on kr_read_storage."""
+        out = np.empty((self.NT + 1, self.K, self.N), np.complex128)
+        for n in range(self.NT + 1):
+            for k in range(self.K):
+                out[n, k] = self.read_storage(which, k, n)
+        return out
+
+    # device-resident chain
+    def set_update_params(self, S, lam):
+        Sc = self._pulses(S, "S")
+        lc = np.ascontiguousarray(lam, np.float64)
+        self._chk(self._lib.kr_set_update_params(self._h, capi.ptr(Sc), capi.ptr(lc)))
+
+    def forward_dev(self, eps_dev_ptr):
+        self._chk(self._lib.kr_forward_dev(self._h, C.c_void_p(eps_dev_ptr)))
+
+    def iteration_functional_dev(self, functional, eps_guess_ptr, eps_new_ptr):
+        self._chk(self._lib.kr_iteration_functional_dev(self._h, int(functional), C.c_void_p(eps_guess_ptr),
+                                                        C.c_void_p(eps_new_ptr)))
+
+    def synchronize(self):
+        self._chk(self._lib.kr_synchronize(self._h))
+
+    def final_states(self):
+        out = np.empty((self.K, self.N), np.complex128)
+        self._chk(self._lib.kr_final_states(self._h, capi.ptr(out)))
+        return out
+
+    def taus(self):
+        out = np.empty(self.K, np.complex128)
+        self._chk(self._lib.kr_taus(self._h, capi.ptr(out)))
+        return out
+
+    def g_a_int(self):
+        out = np.empty(self.L)
+        self._chk(self._lib.kr_g_a_int(self._h, capi.ptr(out)))
+        return out
+
+    def enable_timing(self, on=True):
+        self._chk(self._lib.kr_enable_timing(self._h, 1 if on else 0))
+
+    def timings_ms(self):
+        t = (C.c_double * 3)()
+        self._chk(self._lib.kr_get_timings(self._h, t))
+        return {"forward": t[0], "backward": t[1], "update": t[2]}
+
+    def info(self):
+        a = (C.c_int32 * 16)()
+        self._chk(self._lib.kr_get_info(self._h, a))
+        keys = ["NP", "workgroups", "traj_per_wg", "threads", "KT", "LMAX", "K_padded", "store_fw", "JQ"]
+        return {k: int(a[i]) for i, k in enumerate(keys)}
+
+    # multi-GPU wiring
+    def ipc_export(self):
+        n = self._lib.kr_ipc_handle_size()
+        buf = (C.c_ubyte * n)()
+        self._chk(self._lib.kr_ipc_export(self._h, buf))
+        return bytes(buf)
+
+    def ipc_connect(self, all_handles):
+        blob = b"".join(all_handles)
+        self._chk(self._lib.kr_ipc_connect(self._h, C.c_char_p(blob)))
