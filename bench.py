@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X Krotov engine.
+
+A "step" = one full Krotov iteration of the hot path on the headline configuration
+(BASELINE.json: N=64 dense Hamiltonian, N_T=1000 intervals, K=256 trajectories, L=2 controls,
+fp64 complex), chained in HBM: tau/chi(T) on the device -> backward sweep -> sequential
+update+forward sweep (kr_iteration_functional_dev).  Pulses, states, targets and storages are
+resident in HBM when the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2|C4]
+  N > 1: launched by torch.distributed.run, one rank per GPU; trajectories are sharded
+  (K per GPU fixed -> weak scaling), the per-step sum of the L update integrands crosses GPUs
+  through in-kernel peer mailboxes over xGMI.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
+the update sweep, durations from HIP events recorded inside libkrotov_hip on its stream) and
+`cpu_baseline` (the plain-C oracle timed on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = matrix peak (spec; MI355X_MICROARCH.md has no fp64 row)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(p, log):
+    """Oracle ("port") on a bounded sample of the same workload: same operators and pulses, fewer
+    trajectories and time steps, executed the way the reference executes it (one dense expm per
+    trajectory per step, serial update sum; use_threads=false -> 1 core).  Unit: state*timesteps/s
+    = 2*K*NT / t_iteration, like the GPU metric."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as oc
+    from krotov_jl_amd import workloads as wl
+    N = p["H0"].shape[0]
+    Ks, NTs = (32, 64) if N >= 64 else (32, 500)
+    Ks = min(Ks, p["psi0"].shape[0])
+    NTs = min(NTs, len(p["tlist"]) - 1)
+    tl = p["tlist"][:NTs + 1]
+    eps, S = p["eps"][:, :NTs], p["S"][:, :NTs]
+    psi0, tgt = p["psi0"][:Ks], p["tgt"][:Ks]
+    out = {}
+    variants = [("reference_order_1thread", 0, 1), ("reference_order_allcores", 0, oc.max_threads()),
+                ("shared_propagator_allcores", 1, oc.max_threads())]
+    for name, mode, nth in variants:
+        t0 = time.perf_counter()
+        psiT, _ = oc.forward(p["H0"], p["Hc"], tl, eps, psi0, store=False, mode=mode, nthreads=nth)
+        t_fw = time.perf_counter() - t0
+        _, _, chiT = wl.chi_and_JT(p["functional"], psiT, tgt)
+        t0 = time.perf_counter()
+        oc.iteration(p["H0"], p["Hc"], tl, eps, S, p["lam"], psi0, chiT, mode=mode, nthreads=nth)
+        t_it = time.perf_counter() - t0
+        out[name] = {"value": 2.0 * Ks * NTs / t_it, "iter_s": t_it, "cores": nth}
+        log("cpu %s: %.3f s/iter on sample K=%d NT=%d (fw %.2fs)" % (name, t_it, Ks, NTs, t_fw))
+    base = out["reference_order_1thread"]
+    return {"value": base["value"], "unit": "state*timesteps/s", "cores": 1, "kind": "port",
+            "sample": "same H0/Hc/pulses, K=%d of %d trajectories, first %d of %d intervals; one Krotov "
+                      "iteration, dense Pade expm per trajectory per step (reference execution order)"
+                      % (Ks, p["psi0"].shape[0], NTs, len(p["tlist"]) - 1),
+            "variants": {k: {"value": v["value"], "cores": v["cores"]} for k, v in out.items()}}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    import torch
+    import krotov_jl_amd as kr
+    from krotov_jl_amd import workloads as wl
+    from krotov_jl_amd import distributed as krd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    p = wl.config(args.config)
+    K_local, N = p["psi0"].shape
+    L, NT = p["eps"].shape
+    K_global = K_local * world
+    if world > 1:
+        # weak scaling: every rank carries its own K_local trajectories (same operators and pulses,
+        # rank-specific states), the functional is normalised by the global K.
+        q = wl.dense_problem(N, NT, K_local, L, 64001 + 1000 * rank, p["tlist"][1] - p["tlist"][0], p["lam"][0])
+        p["psi0"], p["tgt"] = q["psi0"], q["tgt"]
+
+    eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K_local, device=local_rank, rank=rank, world=world,
+                       K_global=K_global)
+    if world > 1:
+        krd.connect_peers(eng, dist)
+    eng.set_initial_states(p["psi0"])
+    eng.set_target_states(p["tgt"])
+    eng.set_update_params(p["S"], p["lam"])
+    func = {"sm": 0, "ss": 1, "re": 2}[p["functional"]]
+    dev = torch.device("cuda", local_rank)
+    eps_a = torch.from_numpy(np.ascontiguousarray(p["eps"])).to(dev)
+    eps_b = torch.empty_like(eps_a)
+    torch.cuda.synchronize()
+    eng.forward_dev(eps_a.data_ptr())
+    eng.synchronize()
+    J0 = wl.chi_and_JT(p["functional"], eng.final_states(), p["tgt"], K_global)[1]
+
+    def sync_all():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_iteration():
+        nonlocal eps_a, eps_b
+        eng.iteration_functional_dev(func, eps_a.data_ptr(), eps_b.data_ptr())
+        eps_a, eps_b = eps_b, eps_a   # pulse ping-pong, optimize.jl:216
+
+    for _ in range(args.warmup):
+        one_iteration()
+    sync_all()
+    eng.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_iteration()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tm = eng.timings_ms()
+    eng.enable_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    J1 = wl.chi_and_JT(p["functional"], eng.final_states(), p["tgt"], K_global)[1]
+    info = eng.info()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        units = 2.0 * K_global * NT            # one backward + one forward state-step per trajectory per interval
+        value = units * args.steps / elapsed
+        # dominant kernel: the update sweep.  Algorithmic flops per (trajectory, interval) unit of that
+        # kernel with a precomputed step propagator: forward apply 8N^2 + L mu-matvecs 8N^2 L
+        # + L dots 8N L.  Propagator construction / polynomial order is overhead, not counted.
+        upd_ms, upd_n = tm["update"]
+        bw_ms, bw_n = tm["backward"]
+        flops_upd = K_local * NT * (8.0 * N * N * (1 + L) + 8.0 * N * L)
+        flops_bw = K_local * NT * (8.0 * N * N)
+        avg_upd = upd_ms / max(upd_n, 1)
+        avg_bw = bw_ms / max(bw_n, 1)
+        achieved = flops_upd / (avg_upd * 1e-3) / 1e12 if upd_n else None
+        line = {
+            "metric": "Krotov iters/sec + state*timesteps/sec, N=64 nt=1000 K=256 traj",
+            "value": value,
+            "unit": "state*timesteps/s",
+            "iters_per_sec": args.steps / elapsed,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s: N=%d dense Hermitian H0 + %d controls, N_T=%d, K=%d trajectories per GPU "
+                                   "(K_global=%d), J_T_%s, lambda_a=%g; one Krotov iteration per step"
+                                   % (args.config, N, L, NT, K_local, K_global, p["functional"], p["lam"][0]),
+                       "parallelism": "trajectories sharded over %d GPU(s); per-step sum of %d doubles" % (world, L),
+                       "engine": info},
+            "roofline": {"bound": "mfma", "kernel": "kr_sweep_update", "achieved": achieved,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": None,
+                         "avg_launch_ms": avg_upd, "launches": upd_n,
+                         "algorithmic_flops_per_launch": flops_upd,
+                         "backward_kernel": {"avg_launch_ms": avg_bw, "launches": bw_n,
+                                             "achieved": (flops_bw / (avg_bw * 1e-3) / 1e12) if bw_n else None},
+                         "note": "fp64 VALU kernel (matrix peak = vector peak for fp64); sequential-latency bound: "
+                                 "N_T dependent steps with one global sum each"},
+            "J_T": {"before": float(J0), "after": float(J1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(p, log)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,12 +134,18 @@ int kr_synchronize(kr_handle *h);
 /* Callback inspection (workspace.jl:24; optimize.jl:258-262): state k at time index n (0..NT). */
 int kr_read_storage(kr_handle *h, int which, int k, int n, double *out /* [N] */);
 
-/* Introspection for bench / tests. info_out: {NP, n_workgroups, traj_per_wg, threads, taylor_order_bw_max,
- * substeps_max, variant, reserved...} (16 ints). timings_ms: last {forward, backward, update} kernel
- * durations measured with HIP events on the handle's stream (3 doubles; <0 = not run).          */
+/* Introspection for bench / tests.  info_out (16 ints): {NP, n_workgroups, traj_per_wg, threads,
+ * KT, LMAX variant, K padded, store_fw, JQ, 0...}.
+ * kr_enable_timing(h, 1) starts a window in which every sweep-kernel launch is bracketed by HIP
+ * events on the handle's stream; kr_get_timings syncs the stream and returns, per kind
+ * {forward, backward, update}: {sum of kernel durations in ms, number of launches} (6 doubles). */
 int kr_get_info(kr_handle *h, int32_t *info_out /* [16] */);
-int kr_get_timings(kr_handle *h, double *timings_ms /* [3] */);
+int kr_get_timings(kr_handle *h, double *timings_ms /* [6] */);
 int kr_enable_timing(kr_handle *h, int on);
+/* Diagnostics (env KROTOV_HIP_STAMPS=1 at kr_create): workgroup 0's accumulated shader cycles of the last
+ * update sweep per phase {matvec+dot, exchange, Taylor, store} and the sweep's length in 100 MHz
+ * ticks; out: 8 x uint64.  Zero when stamps are off.                                              */
+int kr_debug_stamps(kr_handle *h, unsigned long long *out);
 
 /* Multi-GPU mailbox wiring (in-kernel per-step exchange of the L partial sums).
  * Each rank exports an IPC handle of its mailbox, the host side all-gathers them

@@ -8,5 +8,6 @@ There is no CPU fallback.
 from . import _capi
 from ._capi import KrotovHipError
 from .engine import HipEngine
+from . import workloads, distributed
 
 __all__ = ["HipEngine", "KrotovHipError", "_capi"]

@@ -22,16 +22,17 @@ struct KrSweepArgs {
     double2 *fin;            // [Kp][N] final states (or nullptr)
     // update sweep only
     const double2 *X;        // [(NT+1)][Kp][N] co-states from the backward sweep
-    const double *S;         // [L][NT]
-    const double *lambda;    // [L]
+    const double *alpha;     // [L][NT] = S[l][n] / lambda[l] (optimize.jl:354), divided once on the host
     double *eps_new;         // [L][NT]
     double *g_a_int;         // [L]
     unsigned long long *mail;  // [2][P][2*LMAX] granules {tag32 | half of a double}
     unsigned long long *xmail; // [2][world][2*LMAX] inter-GPU granules (local memory, peers write)
     unsigned long long *peer_xmail[8]; // every rank's xmail (peer_xmail[rank] == xmail)
     unsigned *status;        // [KR_STATUS_WORDS]
+    unsigned long long *debug; // nullptr, or [8]: workgroup 0's cycle counts per phase (diagnostics only)
     double nrm[1 + KR_LMAX_CAP]; // 2-norm bounds of H0, H_1..H_L
     double tol;
+    double thr[KR_MAX_ORDER];    // thr[m] = largest theta <= KR_THETA_MAX for which Taylor order m meets tol
     unsigned present_mask;   // bit l set: control l has a derivative (optimize.jl:344)
     int N, NT, Kp, L;
     int dir;                 // +1 forward (store slot n+1), -1 backward (store slot n)
@@ -56,6 +57,26 @@ __host__ __device__ inline void kr_taylor_plan(double theta, double tol, int &s,
         const double rem = next / (1.0 - th / (double)(m + 2));
         if (rem <= budget) break;
         term = next;
+    }
+}
+
+// 1/j, j = 0..KR_MAX_ORDER (index 0 unused): the Horner coefficients without an fp64 division
+__device__ __constant__ static const double kr_rinv[KR_MAX_ORDER + 1] = {
+    0.0, 1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11, 1.0 / 12,
+    1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18, 1.0 / 19, 1.0 / 20, 1.0 / 21, 1.0 / 22, 1.0 / 23,
+    1.0 / 24, 1.0 / 25, 1.0 / 26, 1.0 / 27, 1.0 / 28, 1.0 / 29, 1.0 / 30, 1.0 / 31, 1.0 / 32, 1.0 / 33, 1.0 / 34,
+    1.0 / 35, 1.0 / 36, 1.0 / 37, 1.0 / 38, 1.0 / 39, 1.0 / 40, 1.0 / 41, 1.0 / 42, 1.0 / 43, 1.0 / 44, 1.0 / 45,
+    1.0 / 46, 1.0 / 47, 1.0 / 48};
+
+// Device-side plan: table lookup for the common single-sub-step case (no fp64 divisions on the
+// critical path), the general routine otherwise.
+__device__ __forceinline__ void kr_plan_fast(const KrSweepArgs &a, const double theta, int &s, int &m) {
+    if (theta <= KR_THETA_MAX) {
+        s = 1;
+        m = 1;
+        while (m < KR_MAX_ORDER - 1 && theta > a.thr[m]) ++m;
+    } else {
+        kr_taylor_plan(theta, a.tol, s, m);
     }
 }
 

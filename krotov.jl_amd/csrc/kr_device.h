@@ -63,11 +63,35 @@ __device__ __forceinline__ double kr_row_sum(double v) {
     return v;
 }
 
-// wave-wide butterfly sum, fixed order (bitwise reproducible, identical in every lane)
+template <int CTRL>
+__device__ __forceinline__ double kr_dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double kr_readlane_f64(const double v, const int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+// wave-wide sum in a fixed order (bitwise reproducible), result uniform in every lane:
+// butterflies inside each row of 16 lanes with DPP, then the four row sums in row order.
 __device__ __forceinline__ double kr_wave_sum(double v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += kr_dpp_mov<0xB1>(v);   // quad_perm:[1,0,3,2]
+    v += kr_dpp_mov<0x4E>(v);   // quad_perm:[2,3,0,1]
+    v += kr_dpp_mov<0x141>(v);  // row_half_mirror
+    v += kr_dpp_mov<0x140>(v);  // row_mirror
+    const double r0 = kr_readlane_f64(v, 0), r1 = kr_readlane_f64(v, 16);
+    const double r2 = kr_readlane_f64(v, 32), r3 = kr_readlane_f64(v, 48);
+    return ((r0 + r1) + r2) + r3;
+}
+
+// 1/j for a wave-uniform j without a memory access: lane j of every wave keeps 1/j in `mine`
+__device__ __forceinline__ double kr_rinv_lane(const double mine, const int j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(mine), j);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(mine), j);
+    return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ unsigned long long kr_realtime() { return __builtin_amdgcn_s_memrealtime(); }
@@ -106,6 +130,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     const int tid = threadIdx.x, wg = blockIdx.x;
     const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
     const bool writer = (jq == 0), row_ok = (i < a.N);
+    const double my_rinv = kr_rinv[(tid & 63) <= KR_MAX_ORDER ? (tid & 63) : 0];
     const int pi_ = i + i / JS;          // padded position of element i
     const int xoff = jq * (JS + 1);      // padded start of this thread's column segment
     const int N = a.N, NT = a.NT, L = a.L;
@@ -141,43 +166,52 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     __syncthreads();
 
     int cur = 0;
+    // pulse values and dt of the NEXT step are fetched one step ahead (off the critical path)
+    double e_nx[LMAX], dt_nx;
+    {
+        const int n0 = (a.dir > 0) ? 0 : (NT - 1);
+        dt_nx = a.dt[n0];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) e_nx[l] = (l < L) ? a.eps[(size_t)l * NT + n0] : 0.0;
+    }
     for (int step = 0; step < NT; ++step) {
         const int n = (a.dir > 0) ? step : (NT - 1 - step);
-        const double sdt = (a.dir > 0) ? a.dt[n] : -a.dt[n];
+        const double sdt = (a.dir > 0) ? dt_nx : -dt_nx;
         double e[LMAX];
         double theta = a.nrm[0];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
-            e[l] = 0.0;
-            if (l < L) {
-                e[l] = a.eps[(size_t)l * NT + n];
-                theta += fabs(e[l]) * a.nrm[1 + l];
-            }
+            e[l] = e_nx[l];
+            if (l < L) theta += fabs(e[l]) * a.nrm[1 + l];
         }
         theta *= fabs(sdt);
+        if (step + 1 < NT) {
+            const int n1 = (a.dir > 0) ? (step + 1) : (NT - 2 - step);
+            dt_nx = a.dt[n1];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) if (l < L) e_nx[l] = a.eps[(size_t)l * NT + n1];
+        }
         int s, m;
-        kr_taylor_plan(theta, a.tol, s, m);
+        kr_plan_fast(a, theta, s, m);
 
         double Er[JS], Ei[JS];
 #pragma unroll
         for (int jj = 0; jj < JS; ++jj) {
             double r = Hr[0][jj], im = Hi[0][jj];
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) {
-                if (l < L) {
-                    r = fma(e[l], Hr[1 + l][jj], r);
-                    im = fma(e[l], Hi[1 + l][jj], im);
-                }
+            for (int l = 0; l < LMAX; ++l) {  // slices beyond L are zero and e[l] = 0 there: no select needed
+                r = fma(e[l], Hr[1 + l][jj], r);
+                im = fma(e[l], Hi[1 + l][jj], im);
             }
             Er[jj] = r;
             Ei[jj] = im;
         }
 
-        const double fs = sdt / (double)s;
+        const double fs = (s == 1) ? sdt : sdt / (double)s;
         for (int sub = 0; sub < s; ++sub) {
             int w = 0;
             for (int j = m; j >= 1; --j) {  // Horner: y <- psi + (-i fs / j) H y
-                const double f = fs / (double)j;
+                const double f = fs * kr_rinv_lane(my_rinv, j);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     const int tq = q * SG + team;
@@ -221,32 +255,25 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 // and sums them in slot order, so every workgroup of every GPU obtains the bitwise identical
 // total.  Slots are double-buffered by step parity; tags increase monotonically over the life of
 // the handle, so nothing needs clearing between launches.  Spins are bounded.
+// Wave 0 issues NO other vector-memory operation in the update kernel (state loads/stores belong
+// to the last wave): vmcnt retires in order, so an HBM load or a store acknowledgement queued in
+// front of the poll would otherwise sit on the critical path of every step.
 // Returns false when the exchange was aborted (status[0] set).
 // =============================================================================================
-template <int LMAX, int NW>
-__device__ __forceinline__ double kr_sum_waves(const double *sred, const int l) {
-    double v = sred[l];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) v += sred[w * LMAX + l];  // fixed order
-    return v;
-}
-
-template <int LMAX, int NW>
-__device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg,
-                                            const double (&part)[LMAX], double (&total)[LMAX],
-                                            double *sred /*[NW*LMAX]*/, double *stot /*[LMAX+1]*/) {
+#define KR_POLL_CHUNKS 4  // slots per lane gathered with all loads in flight at once (P <= 256 in one go)
+template <int LMAX>
+__device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg, const bool writer,
+                                            const int rowid, const double (&part)[LMAX], double (&total)[LMAX],
+                                            double *spart /*[LMAX][64]*/, double *stot /*[LMAX+1]*/) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, P = a.P;
     const unsigned tag = a.epoch_base + (unsigned)n + 1u;
     const int par = n & 1;
 
-    // 1. workgroup partial: wave sums, then the four waves in fixed order
-    double wsum[LMAX];
+    // 1. the 64 row owners of the workgroup deposit their partial sums
+    if (writer) {
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) wsum[l] = (l < L) ? kr_wave_sum(part[l]) : 0.0;
-    if (lane == 0) {
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) sred[wave * LMAX + l] = wsum[l];
+        for (int l = 0; l < LMAX; ++l) if (l < L) spart[l * 64 + rowid] = part[l];
     }
     __syncthreads();
 
@@ -254,17 +281,14 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         bool ok_all = true;
         double tot[LMAX];
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
-        if (P == 1 && a.world == 1) {
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l)
-                tot[l] = kr_sum_waves<LMAX, NW>(sred, l);
-        } else {
+        for (int l = 0; l < LMAX; ++l) tot[l] = (l < L) ? kr_wave_sum(spart[l * 64 + lane]) : 0.0;  // workgroup partial
+        if (!(P == 1 && a.world == 1)) {
             // 2. publish this workgroup's partial
             kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)par * P + wg) * (2 * LMAX));
             if (lane < 2 * L) {
-                const int l = lane >> 1;
-                const double v = kr_sum_waves<LMAX, NW>(sred, l);
+                double v = 0.0;
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) if (l == (lane >> 1)) v = tot[l];
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
                 const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
                 __hip_atomic_store(slot + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
@@ -277,16 +301,33 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 bool ok = true;
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
-                for (int q = lane; q < P; q += 64) {
-                    kr_gu64 *sq = (kr_gu64 *)(a.mail + ((size_t)par * P + q) * (2 * LMAX));
+                for (int q0 = 0; q0 < P; q0 += 64 * KR_POLL_CHUNKS) {
+                    // issue every load of the pass back to back (no data-dependent branch in between), wait once
+                    unsigned long long g[KR_POLL_CHUNKS][2 * LMAX];
 #pragma unroll
-                    for (int l = 0; l < LMAX; ++l) {
-                        if (l < L) {
-                            const unsigned long long g0 = __hip_atomic_load(sq + 2 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const unsigned long long g1 = __hip_atomic_load(sq + 2 * l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = ok && ((unsigned)(g0 >> 32) == tag) && ((unsigned)(g1 >> 32) == tag);
-                            const unsigned long long bits = (g1 << 32) | (g0 & 0xffffffffull);
-                            tot[l] += __longlong_as_double((long long)bits);
+                    for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
+                        if (q0 + 64 * c < P) {  // wave-uniform
+                            const int q = min(q0 + 64 * c + lane, P - 1);
+                            kr_gu64 *sq = (kr_gu64 *)(a.mail + ((size_t)par * P + q) * (2 * LMAX));
+#pragma unroll
+                            for (int w = 0; w < 2 * LMAX; ++w)
+                                g[c][w] = __hip_atomic_load(sq + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
+                        if (q0 + 64 * c < P) {
+                            const bool mine = (q0 + 64 * c + lane) < P;
+#pragma unroll
+                            for (int l = 0; l < LMAX; ++l) {
+                                if (l < L) {
+                                    const unsigned long long g0 = g[c][2 * l], g1 = g[c][2 * l + 1];
+                                    const bool good = ((unsigned)(g0 >> 32) == tag) & ((unsigned)(g1 >> 32) == tag);
+                                    ok = ok & (good | !mine);
+                                    const unsigned long long bits = (g1 << 32) | (g0 & 0xffffffffull);
+                                    tot[l] += mine ? __longlong_as_double((long long)bits) : 0.0;
+                                }
+                            }
                         }
                     }
                 }
@@ -376,23 +417,32 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 
 // =============================================================================================
 // Update sweep (optimize.jl:321-370): strictly sequential in n, one global sum per step.
+// Wave roles: wave 0 runs the exchange; the LAST wave moves states between HBM and LDS
+// (chi(t_{n+1}) prefetch, forward-storage writes); every wave takes part in the matvecs.
 // =============================================================================================
 template <int NP, int LMAX, int KT>
 __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, KT>::THREADS / 256)) void kr_sweep_update(const KrSweepArgs a) {
     using G = KrGeom<NP, LMAX, KT>;
     constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, KTILE = G::KTILE, NPP = G::NPP, NW = G::NW;
+    constexpr int CH = (KTILE * NP + 63) / 64;  // 16-B elements per lane when one wave moves a whole tile
     __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];
     __shared__ __attribute__((aligned(16))) double2 sy[2][KTILE][NPP];
-    __shared__ double sred[NW * LMAX];
+    __shared__ __attribute__((aligned(16))) double2 sc[2][KTILE][NP];  // chi(t_n) of this tile, by step parity
+    __shared__ double spart[LMAX * 64];
     __shared__ double stot[LMAX + 1];
 
-    const int tid = threadIdx.x, wg = blockIdx.x;
+    const int tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
     const bool writer = (jq == 0), row_ok = (i < a.N);
+    const bool memwave = (wave == NW - 1);
+    const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
+    const int rowid = tid / JQ;  // 0..63
     const int pi_ = i + i / JS;
     const int xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
+    const size_t tile_base = (size_t)wg * KTILE * N;  // the tile's trajectories are contiguous in every [Kp][N] slab
+    const int tile_elems = KTILE * N;
 
     double Hr[LMAX + 1][JS], Hi[LMAX + 1][JS];
 #pragma unroll
@@ -406,29 +456,65 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         }
     }
 
-    double pr[KT], pim[KT], cr[KT], ci[KT];
-    size_t kbase[KT];
+    // memory wave: element e = lane + 64 c of the tile <-> (trajectory tq, row i)
+    int m_tq[CH], m_i[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int e = lane + 64 * c;
+        m_tq[c] = (e < tile_elems) ? e / N : -1;
+        m_i[c] = (e < tile_elems) ? e % N : 0;
+    }
+    double2 cpf[CH];  // chi prefetch registers (memory wave)
+
+    double pr[KT], pim[KT];
 #pragma unroll
     for (int q = 0; q < KT; ++q) {
-        const int k = wg * KTILE + q * SG + team;
-        kbase[q] = (size_t)k * N;
-        double2 v = make_double2(0.0, 0.0), c = make_double2(0.0, 0.0);
-        if (row_ok) {
-            v = a.init[kbase[q] + i];
-            c = a.X[kbase[q] + i];  // chi_k(t_0)
+        const int tq = q * SG + team;
+        double2 v = make_double2(0.0, 0.0);
+        if (row_ok) v = a.init[tile_base + (size_t)tq * N + i];
+        pr[q] = v.x; pim[q] = v.y;
+        if (writer) {
+            sx[0][tq][pi_] = v;
+            double2 c = make_double2(0.0, 0.0);
+            if (row_ok) c = a.X[tile_base + (size_t)tq * N + i];  // chi_k(t_0)
+            sc[0][tq][i] = c;
+            sc[1][tq][i] = make_double2(0.0, 0.0);
         }
-        pr[q] = v.x; pim[q] = v.y; cr[q] = c.x; ci[q] = c.y;
-        if (writer) sx[0][q * SG + team][pi_] = v;
-        if (a.store && writer && row_ok) a.store[kbase[q] + i] = v;
+    }
+    if (memwave && a.store) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (m_tq[c] >= 0) a.store[tile_base + lane + 64 * c] = a.init[tile_base + lane + 64 * c];
     }
     double gint[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) gint[l] = 0.0;
     __syncthreads();
 
+    // optional phase stamps of workgroup 0 (diagnostic runs only; a.debug == nullptr otherwise)
+    const bool stamp = (a.debug != nullptr) && (wg == 0);
+    unsigned long long tA = 0, tX = 0, tB = 0, tS = 0, t_prev = 0, rt0 = 0;
+    if (stamp) { t_prev = __builtin_amdgcn_s_memtime(); rt0 = kr_realtime(); }
     int cur = 0;
+    // guess pulse, step size alpha = S/lambda and dt of the NEXT step are fetched one step ahead
+    double eg_nx[LMAX], al_nx[LMAX], dt_nx = a.dt[0];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        eg_nx[l] = (l < L) ? a.eps[(size_t)l * NT] : 0.0;
+        al_nx[l] = (l < L) ? a.alpha[(size_t)l * NT] : 0.0;
+    }
     for (int n = 0; n < NT; ++n) {
-        const double dt = a.dt[n];
+        const double dt = dt_nx;
+        double eg[LMAX], al[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { eg[l] = eg_nx[l]; al[l] = al_nx[l]; }
+        if (n + 1 < NT) {
+            dt_nx = a.dt[n + 1];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l < L) { eg_nx[l] = a.eps[(size_t)l * NT + n + 1]; al_nx[l] = a.alpha[(size_t)l * NT + n + 1]; }
+            }
+        }
         // ---- phase A: a_m = H_m psi (m = 0..L) and the partial sums Im<chi|H_l|psi> ----------
         double a0r[KT], a0i[KT], alr[KT][LMAX], ali[KT][LMAX];
         double part[LMAX];
@@ -438,6 +524,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         for (int q = 0; q < KT; ++q) {
             const int tq = q * SG + team;
             const double2 *src = &sx[cur][tq][xoff];
+            const double2 chi = sc[n & 1][tq][i];
             kr_row_dot<JS, JQ>(Hr[0], Hi[0], src, a0r[q], a0i[q]);
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) {
@@ -445,22 +532,23 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 if (l < L) {
                     kr_row_dot<JS, JQ>(Hr[1 + l], Hi[1 + l], src, alr[q][l], ali[q][l]);
                     // Im(conj(chi) * a) = chi_r a_i - chi_i a_r ; one lane per row contributes
-                    if (writer && ((a.present_mask >> l) & 1u)) part[l] += cr[q] * ali[q][l] - ci[q] * alr[q][l];
+                    if ((a.present_mask >> l) & 1u) part[l] += chi.x * ali[q][l] - chi.y * alr[q][l];
                 }
             }
         }
-        // prefetch chi(t_{n+1}) for the next step; it lands during the exchange / Taylor phase
-        if (n + 1 < NT && row_ok) {
-#pragma unroll
-            for (int q = 0; q < KT; ++q) {
-                const double2 c = a.X[(size_t)(n + 1) * slab + kbase[q] + i];
-                cr[q] = c.x; ci[q] = c.y;
-            }
-        }
+        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tA += t - t_prev; t_prev = t; }
 
         // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
         double du[LMAX];
-        if (!kr_exchange<LMAX, NW>(a, n, wg, part, du, sred, stot)) return;
+        if (!kr_exchange<LMAX>(a, n, wg, writer, rowid, part, du, spart, stot)) return;
+        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
+
+        // memory wave: start fetching chi(t_{n+1}); it lands while the Taylor rounds run
+        if (memwave && n + 1 < NT) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (m_tq[c] >= 0) cpf[c] = a.X[(size_t)(n + 1) * slab + tile_base + lane + 64 * c];
+        }
 
         // ---- pulse update (optimize.jl:351-358), identical on every workgroup ---------------
         double e[LMAX];
@@ -469,29 +557,27 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         for (int l = 0; l < LMAX; ++l) {
             e[l] = 0.0;
             if (l < L) {
-                const double alpha = __ddiv_rn(a.S[(size_t)l * NT + n], a.lambda[l]);
+                const double alpha = al[l];  // = S[l][n] / lambda[l], IEEE division done once on the host
                 const double deps = __dmul_rn(alpha, du[l]);
-                e[l] = __dadd_rn(a.eps[(size_t)l * NT + n], deps);
+                e[l] = __dadd_rn(eg[l], deps);
                 const double ad = fabs(du[l]);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dt));
                 theta += fabs(e[l]) * a.nrm[1 + l];
-                if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = e[l];
+                if (wg == 0 && memwave && lane == 0) a.eps_new[(size_t)l * NT + n] = e[l];
             }
         }
         theta *= fabs(dt);
         int s, m;
-        kr_taylor_plan(theta, a.tol, s, m);
+        kr_plan_fast(a, theta, s, m);
 
         double Er[JS], Ei[JS];
 #pragma unroll
         for (int jj = 0; jj < JS; ++jj) {
             double r = Hr[0][jj], im = Hi[0][jj];
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) {
-                if (l < L) {
-                    r = fma(e[l], Hr[1 + l][jj], r);
-                    im = fma(e[l], Hi[1 + l][jj], im);
-                }
+            for (int l = 0; l < LMAX; ++l) {  // slices beyond L are zero and e[l] = 0 there: no select needed
+                r = fma(e[l], Hr[1 + l][jj], r);
+                im = fma(e[l], Hi[1 + l][jj], im);
             }
             Er[jj] = r;
             Ei[jj] = im;
@@ -500,16 +586,14 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         // ---- phase B: psi <- exp(-i H dt) psi.  The first application H psi = a0 + sum e_l a_l
         //      is already known, so sub-step 0 costs m-1 matvecs:
         //      psi' = psi + y1,  y_m = v,  y_{j-1} = v + (-i fs / j) H y_j,  v = -i fs (H psi)
-        const double fs = dt / (double)s;
+        const double fs = (s == 1) ? dt : dt / (double)s;
         {
             double vr[KT], vi[KT];
 #pragma unroll
             for (int q = 0; q < KT; ++q) {
                 double wr = a0r[q], wi = a0i[q];
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l) {
-                    if (l < L) { wr = fma(e[l], alr[q][l], wr); wi = fma(e[l], ali[q][l], wi); }
-                }
+                for (int l = 0; l < LMAX; ++l) { wr = fma(e[l], alr[q][l], wr); wi = fma(e[l], ali[q][l], wi); }
                 vr[q] = fs * wi;   // -i (wr + i wi) = wi - i wr
                 vi[q] = -fs * wr;
                 if (m > 1 && writer) sy[0][q * SG + team][pi_] = make_double2(vr[q], vi[q]);
@@ -520,7 +604,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
             for (int q = 0; q < KT; ++q) { yr[q] = vr[q]; yi[q] = vi[q]; }
             for (int j = m; j >= 2; --j) {
-                const double f = fs / (double)j;
+                const double f = fs * kr_rinv_lane(my_rinv, j);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     const int tq = q * SG + team;
@@ -539,13 +623,17 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 pim[q] += yi[q];
                 if (writer) sx[cur ^ 1][q * SG + team][pi_] = make_double2(pr[q], pim[q]);
             }
+            if (s == 1 && memwave && n + 1 < NT) {  // hand chi(t_{n+1}) to the row owners of the next step
+#pragma unroll
+                for (int c = 0; c < CH; ++c) if (m_tq[c] >= 0) sc[(n + 1) & 1][m_tq[c]][m_i[c]] = cpf[c];
+            }
             __syncthreads();
             cur ^= 1;
         }
         for (int sub = 1; sub < s; ++sub) {  // further sub-steps (only when ||H dt|| > KR_THETA_MAX)
             int w = 0;
             for (int j = m; j >= 1; --j) {
-                const double f = fs / (double)j;
+                const double f = fs * kr_rinv_lane(my_rinv, j);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     const int tq = q * SG + team;
@@ -561,21 +649,36 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                         if (writer) sx[cur ^ 1][tq][pi_] = make_double2(y_r, y_i);
                     }
                 }
+                if (j == 1 && sub == s - 1 && memwave && n + 1 < NT) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) if (m_tq[c] >= 0) sc[(n + 1) & 1][m_tq[c]][m_i[c]] = cpf[c];
+                }
                 __syncthreads();
                 w ^= 1;
             }
             cur ^= 1;
         }
+        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB += t - t_prev; t_prev = t; }
 
-        if (a.store && writer && row_ok) {
+        // memory wave: forward storage slot n+1 <- psi(t_{n+1}) (coalesced 16-B stores from LDS)
+        if (memwave && a.store) {
 #pragma unroll
-            for (int q = 0; q < KT; ++q)
-                a.store[(size_t)(n + 1) * slab + kbase[q] + i] = make_double2(pr[q], pim[q]);
+            for (int c = 0; c < CH; ++c) {
+                if (m_tq[c] >= 0) {
+                    const int ii = m_i[c];
+                    a.store[(size_t)(n + 1) * slab + tile_base + lane + 64 * c] = sx[cur][m_tq[c]][ii + ii / JS];
+                }
+            }
         }
+        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tS += t - t_prev; t_prev = t; }
+    }
+    if (stamp && tid == 0) {
+        a.debug[0] = tA; a.debug[1] = tX; a.debug[2] = tB; a.debug[3] = tS;
+        a.debug[4] = kr_realtime() - rt0;
     }
     if (a.fin && writer && row_ok) {
 #pragma unroll
-        for (int q = 0; q < KT; ++q) a.fin[kbase[q] + i] = make_double2(pr[q], pim[q]);
+        for (int q = 0; q < KT; ++q) a.fin[tile_base + (size_t)(q * SG + team) * N + i] = make_double2(pr[q], pim[q]);
     }
     if (wg == 0 && tid == 0) {
 #pragma unroll

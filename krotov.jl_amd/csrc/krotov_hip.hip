@@ -38,6 +38,7 @@ struct kr_handle {
     bool store_fw = true;
     double tol = 1e-16;
     double nrm_fw[1 + KR_LMAX_CAP]{}, nrm_bw[1 + KR_LMAX_CAP]{};
+    double thr[KR_MAX_ORDER]{};
     unsigned present_mask = 0;
     // device buffers
     double2 *Hpack_fw = nullptr, *Hpack_bw = nullptr;
@@ -48,12 +49,15 @@ struct kr_handle {
     unsigned long long *peer_xmail[8]{};
     bool peers_connected = false;
     unsigned *status_d = nullptr;
+    unsigned long long *debug_d = nullptr;
+    bool debug_on = false;
     unsigned epoch_base = 0;
     bool have_psi0 = false, have_tgt = false, have_X = false, have_final = false, have_params = false;
-    // timing
+    // timing: per kind (0 forward, 1 backward, 2 update) a pool of event pairs, one per launch since
+    // the last reset; durations are read back (after a stream sync) by kr_get_timings
     bool timing = false;
-    hipEvent_t ev[6]{};
-    bool ev_used[3]{false, false, false};
+    std::vector<hipEvent_t> ev[3];
+    size_t ev_n[3]{0, 0, 0};
     // host staging
     std::vector<double> stage;
 };
@@ -221,13 +225,13 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
-                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d};
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected)
         for (int r = 0; r < h->cfg.world; ++r)
             if (r != h->cfg.rank && h->peer_xmail[r]) (void)hipIpcCloseMemHandle(h->peer_xmail[r]);
     if (h->xmail_d) (void)hipFree(h->xmail_d);
-    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &pool : h->ev) for (auto &e : pool) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
@@ -272,6 +276,22 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     h->device = dev;
     h->store_fw = !(cfg->flags & KR_NO_STORE_FW);
     h->tol = (cfg->prop_tol > 0) ? cfg->prop_tol : 1e-16;
+    {   // thr[m]: largest theta in [0, KR_THETA_MAX] whose order-m remainder bound meets tol (bisection)
+        const char *et = getenv("KROTOV_HIP_TOL");
+        if (et && atof(et) > 0) h->tol = atof(et);
+        for (int m = 1; m < KR_MAX_ORDER; ++m) {
+            auto rem = [&](double th) {
+                double term = th;
+                for (int q = 1; q <= m; ++q) term = term * th / (double)(q + 1);
+                return term / (1.0 - th / (double)(m + 2));
+            };
+            double lo = 0.0, hi = KR_THETA_MAX;
+            if (rem(hi) <= h->tol) lo = hi;
+            else for (int it = 0; it < 100; ++it) { const double mid = 0.5 * (lo + hi); if (rem(mid) <= h->tol) lo = mid; else hi = mid; }
+            h->thr[m] = lo;
+        }
+        h->thr[0] = 0.0;
+    }
     int rc = KR_OK;
     auto bail = [&](int code) { g_create_error = h->err; (void)hipSetDevice(dev); free_all(h); delete h; return code; };
 #define CHK(call) do { hipError_t e2_ = (call); if (e2_ != hipSuccess) { fail(h, KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2_)); return bail(KR_ERR_HIP); } } while (0)
@@ -280,7 +300,6 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     if (rc != KR_OK) return bail(rc);
     CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    for (auto &ev : h->ev) CHK(hipEventCreate(&ev));
 
     const int N = cfg->N, NT = cfg->NT, L = cfg->L, NP = h->NP;
     const size_t nn = (size_t)N * N;
@@ -328,6 +347,9 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     const size_t mail_words = (size_t)2 * h->P * 2 * KR_LMAX_CAP;
     CHK(dalloc(&h->mail_d, mail_words));
     CHK(hipMemset(h->mail_d, 0, mail_words * sizeof(unsigned long long)));
+    CHK(dalloc(&h->debug_d, 8));
+    CHK(hipMemset(h->debug_d, 0, 8 * sizeof(unsigned long long)));
+    h->debug_on = env_int("KROTOV_HIP_STAMPS", 0) != 0;
     CHK(dalloc(&h->status_d, KR_STATUS_WORDS));
     CHK(hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
     if (cfg->world > 1) {
@@ -352,7 +374,23 @@ extern "C" int kr_set_stream(kr_handle *h, void *hip_stream) {
 
 extern "C" int kr_enable_timing(kr_handle *h, int on) {
     if (!h) return KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
     h->timing = on != 0;
+    for (auto &n : h->ev_n) n = 0;  // (re)start the accumulation window
+    return KR_OK;
+}
+
+static int ev_mark(kr_handle *h, int kind, bool end) {
+    if (!h->timing) return KR_OK;
+    if (h->ev_n[kind] >= 4096) return KR_OK;  // window full: stop recording, keep what we have
+    const size_t idx = 2 * h->ev_n[kind] + (end ? 1 : 0);
+    while (h->ev[kind].size() <= idx) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        h->ev[kind].push_back(e);
+    }
+    HIPCHK(h, hipEventRecord(h->ev[kind][idx], h->stream));
+    if (end) h->ev_n[kind]++;
     return KR_OK;
 }
 
@@ -362,12 +400,14 @@ extern "C" int kr_get_timings(kr_handle *h, double *t) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 3; ++i) {
-        t[i] = -1.0;
-        if (h->ev_used[i]) {
+        double sum = 0;
+        for (size_t q = 0; q < h->ev_n[i]; ++q) {
             float ms = 0;
-            HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
-            t[i] = ms;
+            HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i][2 * q], h->ev[i][2 * q + 1]));
+            sum += ms;
         }
+        t[2 * i] = sum;
+        t[2 * i + 1] = (double)h->ev_n[i];
     }
     return KR_OK;
 }
@@ -378,6 +418,15 @@ extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
     info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ;
     // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
+    return KR_OK;
+}
+
+extern "C" int kr_debug_stamps(kr_handle *h, unsigned long long *out) {
+    if (!h || !out) return KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->debug_d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return KR_OK;
 }
 
@@ -415,8 +464,10 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.N = h->cfg.N; a.NT = h->cfg.NT; a.Kp = h->Kp; a.L = h->cfg.L;
     a.P = h->P; a.rank = h->cfg.rank; a.world = h->cfg.world;
     a.tol = h->tol;
+    memcpy(a.thr, h->thr, sizeof a.thr);
     a.present_mask = h->present_mask;
     a.status = h->status_d;
+    a.debug = h->debug_on ? h->debug_d : nullptr;
     a.mail = h->mail_d;
     a.xmail = h->xmail_d;
     for (int r = 0; r < 8; ++r) a.peer_xmail[r] = h->peer_xmail[r];
@@ -430,10 +481,10 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     a.eps = eps_dev;
     a.init = init; a.store = store; a.fin = fin;
     a.dir = backward ? -1 : +1;
-    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2 * which_ev], h->stream));
+    int rc = ev_mark(h, which_ev, false);
+    if (rc) return rc;
     HIPCHK(h, h->launch(h->LMAXv, h->KT, 0, h->P, h->stream, &a));
-    if (h->timing) { HIPCHK(h, hipEventRecord(h->ev[2 * which_ev + 1], h->stream)); h->ev_used[which_ev] = true; }
-    return KR_OK;
+    return ev_mark(h, which_ev, true);
 }
 
 static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_new_dev) {
@@ -445,16 +496,16 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     memcpy(a.nrm, h->nrm_fw, sizeof a.nrm);
     a.eps = eps_guess_dev;
     a.init = h->psi0_d; a.store = h->store_fw ? h->Phi_d : nullptr; a.fin = h->psiT_d;
-    a.X = h->X_d; a.S = h->S_d; a.lambda = h->lambda_d; a.eps_new = eps_new_dev; a.g_a_int = h->gint_d;
+    a.X = h->X_d; a.alpha = h->S_d; a.eps_new = eps_new_dev; a.g_a_int = h->gint_d;
     a.dir = +1;
     a.epoch_base = h->epoch_base;
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
     if (h->epoch_base > 0xfff00000u) h->epoch_base = 0;  // (tags restart; mailboxes hold older, larger tags only transiently)
     HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
-    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+    int rc = ev_mark(h, 2, false);
+    if (rc) return rc;
     HIPCHK(h, h->launch(h->LMAXv, h->KT, 1, h->P, h->stream, &a));
-    if (h->timing) { HIPCHK(h, hipEventRecord(h->ev[5], h->stream)); h->ev_used[2] = true; }
-    return KR_OK;
+    return ev_mark(h, 2, true);
 }
 
 static int check_status(kr_handle *h) {
@@ -506,8 +557,13 @@ extern "C" int kr_backward(kr_handle *h, const double *eps_guess, const double *
 static int set_params_locked(kr_handle *h, const double *S, const double *lambda) {
     for (int l = 0; l < h->cfg.L; ++l)
         if (!(lambda[l] != 0.0)) return fail(h, KR_ERR_INVALID, "lambda[%d] must be non-zero", l);
-    HIPCHK(h, hipMemcpyAsync(h->S_d, S, (size_t)h->cfg.L * h->cfg.NT * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->lambda_d, lambda, h->cfg.L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // alpha[l][n] = S[l][n] / lambda[l] exactly as optimize.jl:354 rounds it (one IEEE division)
+    const int L = h->cfg.L, NT = h->cfg.NT;
+    h->stage.resize((size_t)L * NT);
+    for (int l = 0; l < L; ++l)
+        for (int n = 0; n < NT; ++n) h->stage[(size_t)l * NT + n] = S[(size_t)l * NT + n] / lambda[l];
+    HIPCHK(h, hipMemcpyAsync(h->S_d, h->stage.data(), (size_t)L * NT * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // stage is reused
     h->have_params = true;
     return KR_OK;
 }

@@ -175,9 +175,15 @@ class HipEngine:
         self._chk(self._lib.kr_enable_timing(self._h, 1 if on else 0))
 
     def timings_ms(self):
-        t = (C.c_double * 3)()
+        """{kind: (sum of kernel durations in ms, launches)} since enable_timing(True)."""
+        t = (C.c_double * 6)()
         self._chk(self._lib.kr_get_timings(self._h, t))
-        return {"forward": t[0], "backward": t[1], "update": t[2]}
+        return {"forward": (t[0], int(t[1])), "backward": (t[2], int(t[3])), "update": (t[4], int(t[5]))}
+
+    def debug_stamps(self):
+        a = (C.c_uint64 * 8)()
+        self._chk(self._lib.kr_debug_stamps(self._h, a))
+        return [int(x) for x in a]
 
     def info(self):
         a = (C.c_int32 * 16)()
