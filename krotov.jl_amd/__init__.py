@@ -8,6 +8,8 @@ There is no CPU fallback.
 from . import _capi
 from ._capi import KrotovHipError
 from .engine import HipEngine
-from . import workloads, distributed
+from . import workloads, distributed, optimize as _optimize_mod
+from .optimize import (ControlProblem, Trajectory, hamiltonian, optimize, optimize_krotov, KrotovResult, KrotovWrk,
+                       J_T_sm, J_T_ss, J_T_re, make_chi, discretize, discretize_on_midpoints, flattop)
 
 __all__ = ["HipEngine", "KrotovHipError", "_capi"]

@@ -204,11 +204,12 @@ def discretize_on_midpoints(control, tlist):
     if len(c) == NT:
         return c.copy()
     if len(c) == NT + 1:
+        # exact inverse of discretize(): c[i] = (v[i-1] + v[i]) / 2  [UPSTREAM-RECALLED; the hand-over tests
+        # test_tls_optimization.jl:126,160 (J_T continuity to 1e-14) only hold if the round trip is exact]
         v = np.empty(NT)
         v[0] = c[0]
-        v[-1] = c[-1]
-        for i in range(1, NT - 1):
-            v[i] = 0.5 * (c[i] + c[i + 1])
+        for i in range(1, NT):
+            v[i] = 2.0 * c[i] - v[i - 1]
         return v
     raise ValueError("control array must have length len(tlist) or len(tlist)-1")
 

@@ -1,0 +1,81 @@
+"""CPU: the C-ABI library loads, exports every symbol include/krotov_hip.h declares, and fails loudly
+without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import krotov_jl_amd as kr
+from krotov_jl_amd import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "krotov_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kr_[a-z_0-9]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    if not os.path.exists(capi.LIB_PATH):
+        ge.build()
+    return capi.load()
+
+
+def test_header_and_binding_agree(lib):
+    declared = _declared_symbols()
+    assert declared == sorted(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_abi_version(lib):
+    assert lib.kr_abi_version() == capi.KR_ABI_VERSION
+
+
+def test_config_struct_layout():
+    # mirrors `struct kr_config` (include/krotov_hip.h): 6 ints, 5 pointers, flags, double, 4 ints, 8 reserved
+    assert C.sizeof(capi.KrConfig) == 24 + 40 + 4 + 4 + 8 + 16 + 32
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_no_controls_is_an_error(lib):
+    """L = 0 -> the reference's message (workspace.jl:72, test_empty_optimization.jl:31-32)."""
+    with pytest.raises(kr.KrotovHipError) as ei:
+        kr.HipEngine(np.eye(2), np.zeros((0, 2, 2)), np.linspace(0, 1, 5), 1)
+    assert "no controls in trajectories: cannot optimize" in str(ei.value)
+    assert ei.value.code == capi.KR_ERR_INVALID
+
+
+def test_bad_arguments_are_rejected(lib):
+    with pytest.raises(kr.KrotovHipError):
+        kr.HipEngine(np.eye(2), np.eye(2)[None], np.array([0.0, 0.1, 0.1, 0.2]), 1)  # tlist not increasing
+
+
+@pytest.mark.skipif(_gpu_present(), reason="a GPU is present")
+def test_fails_loudly_without_gpu(lib):
+    with pytest.raises(kr.KrotovHipError) as ei:
+        kr.HipEngine(np.eye(2), np.eye(2)[None], np.linspace(0, 1, 5), 1)
+    assert ei.value.code == capi.KR_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "krotov.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle_c" not in src and "krotov_oracle" not in src, f

@@ -92,3 +92,139 @@ def test_c3_reduced_time(oracle_c):
     p = wl.dense_problem(64, 40, 256, 2, 64001, 0.05, 5.0)
     info = _run_case(oracle_c, p, check_storage=False)
     assert info["NP"] == 64 and info["workgroups"] == 256
+
+
+def test_golden_fixtures_on_gpu():
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name in ("hermitian_n16", "nonhermitian_n8"):
+        g = np.load(os.path.join(gold, name + ".npz"))
+        K = g["psi0"].shape[0]
+        with kr.HipEngine(g["H0"], g["Hc"], g["tlist"], K) as eng:
+            eng.set_initial_states(g["psi0"])
+            assert np.max(np.abs(eng.forward(g["eps"]) - g["psiT0"])) < TOL_STATE
+            eps_new, ga, psiT1 = eng.iteration(g["eps"], g["chiT"], g["S"], g["lam"])
+            assert _rel(eps_new, g["eps_new"]) < TOL_PULSE
+            assert _rel(ga, g["g_a_int"]) < 1e-9
+            assert np.max(np.abs(psiT1 - g["psiT1"])) < 1e-10
+            NT = len(g["tlist"]) - 1
+            for k in range(K):
+                assert np.max(np.abs(eng.read_storage("bw", k, 0) - g["X0"][k])) < TOL_STATE
+                assert np.max(np.abs(eng.read_storage("bw", k, NT // 2) - g["X_mid"][k])) < TOL_STATE
+                assert np.max(np.abs(eng.read_storage("fw", k, NT) - psiT1[k])) == 0.0
+
+
+def test_tls_optimization_through_driver_on_gpu():
+    """test_tls_optimization.jl:47-70 through the host mirror of optimize(problem; method=Krotov) with the
+    HIP engine: the reference's own thresholds, and the TLS golden pulses."""
+    import io
+    import os
+    eps = lambda t: 0.2 * kr.flattop(t, T=5, t_rise=0.3)
+    H = kr.hamiltonian(-0.5 * np.array([[1, 0], [0, -1]], complex), (np.array([[0, 1], [1, 0]], complex), eps))
+    tlist = np.linspace(0, 5, 501)
+    traj = kr.Trajectory(np.array([1, 0], complex), H, target_state=np.array([0, 1], complex))
+    snapshots = {}
+
+    def grab(wrk, it, eps_ip1, eps_i):
+        snapshots[it] = eps_ip1[0].copy()
+    problem = kr.ControlProblem([traj], tlist, iter_stop=5, J_T=kr.J_T_sm)
+    res = kr.optimize(problem, method="Krotov", callback=grab, print_iters_out=io.StringIO())
+    assert res.J_T < 1e-3
+    assert 1.0 < np.max(np.abs(res.optimized_controls[0])) < 1.2
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tls_kat.npz"))
+    assert np.max(np.abs(snapshots[1] - g["pulse_iter1"])) < 1e-10
+    assert np.max(np.abs(snapshots[5] - g["pulse_iter5"])) < 1e-8
+    assert abs(res.J_T - g["J_T"][5]) < 1e-10
+
+
+def test_device_functional_chain_matches_host_chain():
+    """kr_iteration_functional_dev (tau, chi(T) on the device, pulses in HBM) against the host-chi path,
+    for J_T_sm / J_T_ss / J_T_re (optimize.jl:297-302,381-386)."""
+    import torch
+    for fname, fid in (("sm", 0), ("ss", 1), ("re", 2)):
+        p = wl.dense_problem(12, 30, 10, 2, 31 + fid, 0.1, 0.5)
+        K = 10
+        with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as a, kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as b:
+            for e in (a, b):
+                e.set_initial_states(p["psi0"])
+                e.set_target_states(p["tgt"])
+            # host chain
+            eps = p["eps"].copy()
+            psiT = a.forward(eps)
+            for _ in range(3):
+                tau, JT, chiT = wl.chi_and_JT(fname, psiT, p["tgt"])
+                eps, ga, psiT = a.iteration(eps, chiT, p["S"], p["lam"])
+            # device chain
+            b.set_update_params(p["S"], p["lam"])
+            e0 = torch.from_numpy(p["eps"].copy()).cuda()
+            e1 = torch.empty_like(e0)
+            torch.cuda.synchronize()
+            b.forward_dev(e0.data_ptr())
+            for _ in range(3):
+                b.iteration_functional_dev(fid, e0.data_ptr(), e1.data_ptr())
+                e0, e1 = e1, e0
+            b.synchronize()
+            assert _rel(e0.cpu().numpy(), eps) < TOL_PULSE
+            assert np.max(np.abs(b.final_states() - psiT)) < 1e-10
+            assert _rel(b.g_a_int(), ga) < 1e-9
+            tau_d = b.taus()
+            assert np.max(np.abs(tau_d - wl.chi_and_JT(fname, psiT, p["tgt"])[0])) < 1e-11
+
+
+def test_absent_control_derivative_is_skipped(oracle_c):
+    """mu_kl === nothing (optimize.jl:344): that control gets no update."""
+    p = wl.dense_problem(8, 20, 3, 2, 55, 0.1, 1.0)
+    K = 3
+    mask = np.array([1, 0], np.uint8)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, hc_present=mask) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+        eps_new, ga, _ = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+    assert np.array_equal(eps_new[1], p["eps"][1]) and ga[1] == 0.0
+    X = oracle_c.backward(p["H0"], p["Hc"], p["tlist"], p["eps"], chiT)
+    eps_o = oracle_c.update_forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], X, mask=mask)[0]
+    assert _rel(eps_new, eps_o) < TOL_PULSE
+
+
+def test_call_order_errors():
+    p = wl.dense_problem(4, 5, 2, 1, 1, 0.1, 1.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 2) as eng:
+        with pytest.raises(kr.KrotovHipError):
+            eng.forward(p["eps"])                       # initial states not set
+        eng.set_initial_states(p["psi0"])
+        with pytest.raises(kr.KrotovHipError):
+            eng.update_forward(p["eps"], p["S"], p["lam"])  # no backward sweep yet
+        with pytest.raises(kr.KrotovHipError):
+            eng.read_storage("bw", 0, 99)
+
+
+def test_full_size_properties_c3():
+    """BASELINE size (N=64, N_T=1000, K=256, L=2): size-independent properties instead of the oracle --
+    norm conservation of every trajectory (Hermitian generator), <chi(t_n)|psi(t_n)> constant along the
+    grid, J_T decreases monotonically over three iterations, run-to-run bitwise reproducibility."""
+    p = wl.config("C3")
+    K = 256
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        assert np.max(np.abs(np.linalg.norm(psiT, axis=1) - 1.0)) < 1e-12
+        eng.backward(p["eps"], p["tgt"])
+        for n in (0, 333, 1000):
+            ov = [np.vdot(eng.read_storage("bw", k, n), eng.read_storage("fw", k, n)) for k in (0, 17, 255)]
+            ovT = [np.vdot(p["tgt"][k], psiT[k]) for k in (0, 17, 255)]
+            assert np.max(np.abs(np.array(ov) - np.array(ovT))) < 1e-12
+        lam = np.full(2, 0.02)
+        eps = p["eps"].copy()
+        J = [wl.chi_and_JT("ss", psiT, p["tgt"])[1]]
+        first = None
+        for it in range(3):
+            _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+            eps_new, ga, psiT = eng.iteration(eps, chiT, p["S"], lam)
+            if it == 0:
+                again = eng.iteration(eps, chiT, p["S"], lam)
+                assert np.array_equal(again[0], eps_new) and np.array_equal(again[2], psiT)
+            eps = eps_new
+            J.append(wl.chi_and_JT("ss", psiT, p["tgt"])[1])
+            assert np.max(np.abs(np.linalg.norm(psiT, axis=1) - 1.0)) < 1e-12
+        assert J[3] < J[2] < J[1] < J[0]
