@@ -1,0 +1,82 @@
+"""GPU: the N > 1 path of the update sweep -- trajectories sharded over ranks, the per-step sum crossing
+ranks through in-kernel peer mailboxes (IPC-mapped, system-scope atomics).  The box has ONE GPU, so the two
+ranks share it (each persistent kernel limited to 64 workgroups so both are resident); this exercises the
+cross-process mailbox protocol, the IPC wiring and the sharded functional normalisation exactly as the
+8-GPU bench uses them.  Result must equal the single-handle, unsharded sweep to 1e-12 (the sum order over
+ranks differs from the single-GPU slot order)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["KROTOV_HIP_MAX_WG"] = "64"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import krotov_jl_amd as kr
+    from krotov_jl_amd import workloads as wl
+    from krotov_jl_amd.distributed import shard_range, connect_peers
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        p = wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0)
+        K = 24
+        a, b = shard_range(K, rank, world)
+        eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], b - a, device=0, rank=rank, world=world, K_global=K)
+        connect_peers(eng, dist)
+        eng.set_initial_states(p["psi0"][a:b])
+        psiT = eng.forward(p["eps"])
+        eps = p["eps"].copy()
+        for _ in range(2):
+            _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"][a:b], K_global=K)
+            dist.barrier()
+            eps, ga, psiT = eng.iteration(eps, chiT, p["S"], p["lam"])
+        q.put((rank, eps, ga, psiT))
+        dist.barrier()
+        eng.close()
+        dist.destroy_process_group()
+    except Exception as exc:  # report instead of hanging the parent
+        q.put((rank, "ERROR: %r" % (exc,), None, None))
+        raise
+
+
+def test_two_ranks_one_gpu_equals_unsharded():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import krotov_jl_amd as kr
+    from krotov_jl_amd import workloads as wl
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = {}
+    for _ in range(2):
+        rank, eps, ga, psiT = q.get(timeout=180)
+        assert not isinstance(eps, str), eps
+        got[rank] = (eps, ga, psiT)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    # both ranks hold the identical updated pulse, bit for bit
+    assert np.array_equal(got[0][0], got[1][0])
+    assert np.array_equal(got[0][1], got[1][1])
+    # unsharded reference on one handle
+    p = wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 24) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        eps = p["eps"].copy()
+        for _ in range(2):
+            _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+            eps, ga, psiT = eng.iteration(eps, chiT, p["S"], p["lam"])
+    assert np.max(np.abs(got[0][0] - eps)) / np.max(np.abs(eps)) < 1e-12
+    assert np.max(np.abs(np.concatenate([got[0][2], got[1][2]]) - psiT)) < 1e-11
+    assert np.max(np.abs(got[0][1] - ga)) / np.max(np.abs(ga)) < 1e-10
