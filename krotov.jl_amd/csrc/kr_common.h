@@ -87,3 +87,5 @@ hipError_t kr_launch_np8(int lmax, int kt, int kind, int grid, hipStream_t s, co
 hipError_t kr_launch_np16(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np32(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np64(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+hipError_t kr_launch_np128(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+hipError_t kr_launch_np256(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);

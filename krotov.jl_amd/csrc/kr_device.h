@@ -26,14 +26,20 @@
 
 template <int NP, int LMAX, int KT>
 struct KrGeom {
-    static constexpr int JQ = (NP >= 64) ? 8 : 4;       // lanes that share one row
-    static constexpr int THREADS = (NP >= 64) ? 512 : 256;  // NP=64: 2 waves/SIMD so the slices fit 256 VGPRs
+    // NP = 64: the four slices H0, H1, H2, H(eps) of a 256-thread team need 256 VGPRs.  For L <= 2 the drift
+    // slice H0 lives in LDS (64 KB, read once per step when H(eps) is formed) and the team stays at 256
+    // threads = one wave per SIMD (fewest non-FMA instructions per matvec round); for L > 2 the team is
+    // widened to 512 threads (2 waves/SIMD, JQ = 8) so that 1+L+1 slices fit the register file.
+    static constexpr bool H0LDS = (NP >= 64) && (LMAX <= 2);
+    static constexpr int THREADS = (NP >= 64 && !H0LDS) ? 512 : 256;
+    static constexpr int JQ = (THREADS == 512) ? 8 : 4;  // lanes that share one row
     static constexpr int NW = THREADS / 64;
     static constexpr int JS = NP / JQ;
     static constexpr int RT = NP * JQ;
     static constexpr int SG = THREADS / RT;
     static constexpr int KTILE = SG * KT;
     static constexpr int NPP = NP + JQ;  // one 16-B pad slot per column segment
+    static constexpr int HREG = H0LDS ? 0 : 1;  // first generator kept in registers (0: H0 in LDS)
     static_assert(NP >= 8 && NP <= 64 && (NP & (NP - 1)) == 0, "NP in {8,16,32,64}");
 };
 
@@ -103,14 +109,18 @@ typedef __attribute__((address_space(1))) unsigned kr_gu32;
 template <int JS, int JQ>
 __device__ __forceinline__ void kr_row_dot(const double (&Er)[JS], const double (&Ei)[JS],
                                            const double2 *__restrict__ xp, double &sr, double &si) {
+    // issue every LDS read of the slice first so that all of them are in flight behind one another
+    // (LDS latency is ~100+ cycles; with only two or three reads in flight the round is latency-bound)
+    double2 x[JS];
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj) x[jj] = xp[jj];
     double a = 0, b = 0, c = 0, d = 0;
 #pragma unroll
     for (int jj = 0; jj < JS; ++jj) {
-        const double2 x = xp[jj];
-        a = fma(Er[jj], x.x, a);
-        b = fma(Ei[jj], x.y, b);
-        c = fma(Er[jj], x.y, c);
-        d = fma(Ei[jj], x.x, d);
+        a = fma(Er[jj], x[jj].x, a);
+        b = fma(Ei[jj], x[jj].y, b);
+        c = fma(Er[jj], x[jj].y, c);
+        d = fma(Ei[jj], x[jj].x, d);
     }
     sr = kr_row_sum<JQ>(a - b);
     si = kr_row_sum<JQ>(c + d);
@@ -126,6 +136,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, KTILE = G::KTILE, NPP = G::NPP;
     __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];
     __shared__ __attribute__((aligned(16))) double2 sy[2][KTILE][NPP];
+    __shared__ __attribute__((aligned(16))) double2 sH0[G::H0LDS ? JS * RT : 1];
 
     const int tid = threadIdx.x, wg = blockIdx.x;
     const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
@@ -135,6 +146,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     const int xoff = jq * (JS + 1);      // padded start of this thread's column segment
     const int N = a.N, NT = a.NT, L = a.L;
 
+    // generator slices: H_1..H_L always in registers; H0 in registers or (H0LDS) in LDS, thread-major
     double Hr[LMAX + 1][JS], Hi[LMAX + 1][JS];
 #pragma unroll
     for (int m = 0; m <= LMAX; ++m) {
@@ -142,8 +154,13 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         for (int jj = 0; jj < JS; ++jj) {
             double2 h = make_double2(0.0, 0.0);
             if (m <= L) h = a.Hpack[((size_t)m * JS + jj) * RT + tt];
-            Hr[m][jj] = h.x;
-            Hi[m][jj] = h.y;
+            if (G::H0LDS && m == 0) {
+                sH0[jj * RT + tt] = h;
+                Hr[m][jj] = 0.0; Hi[m][jj] = 0.0;  // dead: never read when H0LDS
+            } else {
+                Hr[m][jj] = h.x;
+                Hi[m][jj] = h.y;
+            }
         }
     }
 
@@ -197,7 +214,9 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         double Er[JS], Ei[JS];
 #pragma unroll
         for (int jj = 0; jj < JS; ++jj) {
-            double r = Hr[0][jj], im = Hi[0][jj];
+            double r, im;
+            if (G::H0LDS) { const double2 h0 = sH0[jj * RT + tt]; r = h0.x; im = h0.y; }
+            else { r = Hr[0][jj]; im = Hi[0][jj]; }
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) {  // slices beyond L are zero and e[l] = 0 there: no select needed
                 r = fma(e[l], Hr[1 + l][jj], r);
@@ -261,19 +280,19 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 // Returns false when the exchange was aborted (status[0] set).
 // =============================================================================================
 #define KR_POLL_CHUNKS 4  // slots per lane gathered with all loads in flight at once (P <= 256 in one go)
-template <int LMAX>
+template <int LMAX, int ROWS>
 __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg, const bool writer,
                                             const int rowid, const double (&part)[LMAX], double (&total)[LMAX],
-                                            double *spart /*[LMAX][64]*/, double *stot /*[LMAX+1]*/) {
+                                            double *spart /*[LMAX][ROWS]*/, double *stot /*[LMAX+1]*/) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, P = a.P;
     const unsigned tag = a.epoch_base + (unsigned)n + 1u;
     const int par = n & 1;
 
-    // 1. the 64 row owners of the workgroup deposit their partial sums
+    // 1. the ROWS row owners of the workgroup deposit their partial sums
     if (writer) {
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) if (l < L) spart[l * 64 + rowid] = part[l];
+        for (int l = 0; l < LMAX; ++l) if (l < L) spart[l * ROWS + rowid] = part[l];
     }
     __syncthreads();
 
@@ -281,7 +300,15 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         bool ok_all = true;
         double tot[LMAX];
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) tot[l] = (l < L) ? kr_wave_sum(spart[l * 64 + lane]) : 0.0;  // workgroup partial
+        for (int l = 0; l < LMAX; ++l) {  // workgroup partial: rows in a fixed order
+            double v = 0.0;
+            if (l < L) {
+#pragma unroll
+                for (int r = 0; r < ROWS; r += 64) v += spart[l * ROWS + r + lane];
+                v = kr_wave_sum(v);
+            }
+            tot[l] = v;
+        }
         if (!(P == 1 && a.world == 1)) {
             // 2. publish this workgroup's partial
             kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)par * P + wg) * (2 * LMAX));
@@ -427,6 +454,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     constexpr int CH = (KTILE * NP + 63) / 64;  // 16-B elements per lane when one wave moves a whole tile
     __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];
     __shared__ __attribute__((aligned(16))) double2 sy[2][KTILE][NPP];
+    __shared__ __attribute__((aligned(16))) double2 sH0[G::H0LDS ? JS * RT : 1];
     __shared__ __attribute__((aligned(16))) double2 sc[2][KTILE][NP];  // chi(t_n) of this tile, by step parity
     __shared__ double spart[LMAX * 64];
     __shared__ double stot[LMAX + 1];
@@ -444,6 +472,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     const size_t tile_base = (size_t)wg * KTILE * N;  // the tile's trajectories are contiguous in every [Kp][N] slab
     const int tile_elems = KTILE * N;
 
+    // generator slices: H_1..H_L always in registers; H0 in registers or (H0LDS) in LDS, thread-major
     double Hr[LMAX + 1][JS], Hi[LMAX + 1][JS];
 #pragma unroll
     for (int m = 0; m <= LMAX; ++m) {
@@ -451,8 +480,13 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         for (int jj = 0; jj < JS; ++jj) {
             double2 h = make_double2(0.0, 0.0);
             if (m <= L) h = a.Hpack[((size_t)m * JS + jj) * RT + tt];
-            Hr[m][jj] = h.x;
-            Hi[m][jj] = h.y;
+            if (G::H0LDS && m == 0) {
+                sH0[jj * RT + tt] = h;
+                Hr[m][jj] = 0.0; Hi[m][jj] = 0.0;  // dead: never read when H0LDS
+            } else {
+                Hr[m][jj] = h.x;
+                Hi[m][jj] = h.y;
+            }
         }
     }
 
@@ -515,7 +549,22 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 if (l < L) { eg_nx[l] = a.eps[(size_t)l * NT + n + 1]; al_nx[l] = a.alpha[(size_t)l * NT + n + 1]; }
             }
         }
-        // ---- phase A: a_m = H_m psi (m = 0..L) and the partial sums Im<chi|H_l|psi> ----------
+        // ---- H(eps_guess) of this step (eps_guess is known in advance; exact, no drift) -----------
+        double Er[JS], Ei[JS];
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) {
+            double r, im;
+            if (G::H0LDS) { const double2 h0 = sH0[jj * RT + tt]; r = h0.x; im = h0.y; }
+            else { r = Hr[0][jj]; im = Hi[0][jj]; }
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                r = fma(eg[l], Hr[1 + l][jj], r);
+                im = fma(eg[l], Hi[1 + l][jj], im);
+            }
+            Er[jj] = r;
+            Ei[jj] = im;
+        }
+        // ---- phase A: b = H(eps_guess) psi, a_l = H_l psi and the partial sums Im<chi|H_l|psi> ----
         double a0r[KT], a0i[KT], alr[KT][LMAX], ali[KT][LMAX];
         double part[LMAX];
 #pragma unroll
@@ -525,7 +574,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
             const int tq = q * SG + team;
             const double2 *src = &sx[cur][tq][xoff];
             const double2 chi = sc[n & 1][tq][i];
-            kr_row_dot<JS, JQ>(Hr[0], Hi[0], src, a0r[q], a0i[q]);
+            kr_row_dot<JS, JQ>(Er, Ei, src, a0r[q], a0i[q]);
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) {
                 alr[q][l] = 0.0; ali[q][l] = 0.0;
@@ -540,7 +589,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 
         // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
         double du[LMAX];
-        if (!kr_exchange<LMAX>(a, n, wg, writer, rowid, part, du, spart, stot)) return;
+        if (!kr_exchange<LMAX, 64>(a, n, wg, writer, rowid, part, du, spart, stot)) return;
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 
         // memory wave: start fetching chi(t_{n+1}); it lands while the Taylor rounds run
@@ -551,15 +600,16 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         }
 
         // ---- pulse update (optimize.jl:351-358), identical on every workgroup ---------------
-        double e[LMAX];
+        double e[LMAX], de[LMAX];
         double theta = a.nrm[0];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
-            e[l] = 0.0;
+            e[l] = 0.0; de[l] = 0.0;
             if (l < L) {
                 const double alpha = al[l];  // = S[l][n] / lambda[l], IEEE division done once on the host
                 const double deps = __dmul_rn(alpha, du[l]);
                 e[l] = __dadd_rn(eg[l], deps);
+                de[l] = e[l] - eg[l];  // what H(eps_guess) has to be corrected by (== deps up to rounding)
                 const double ad = fabs(du[l]);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dt));
                 theta += fabs(e[l]) * a.nrm[1 + l];
@@ -570,20 +620,17 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         int s, m;
         kr_plan_fast(a, theta, s, m);
 
-        double Er[JS], Ei[JS];
+        // H(eps_new) = H(eps_guess) + sum_l (eps_new - eps_guess)_l H_l   (H(eps_guess) was formed before phase A)
 #pragma unroll
         for (int jj = 0; jj < JS; ++jj) {
-            double r = Hr[0][jj], im = Hi[0][jj];
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) {  // slices beyond L are zero and e[l] = 0 there: no select needed
-                r = fma(e[l], Hr[1 + l][jj], r);
-                im = fma(e[l], Hi[1 + l][jj], im);
+            for (int l = 0; l < LMAX; ++l) {
+                Er[jj] = fma(de[l], Hr[1 + l][jj], Er[jj]);
+                Ei[jj] = fma(de[l], Hi[1 + l][jj], Ei[jj]);
             }
-            Er[jj] = r;
-            Ei[jj] = im;
         }
 
-        // ---- phase B: psi <- exp(-i H dt) psi.  The first application H psi = a0 + sum e_l a_l
+        // ---- phase B: psi <- exp(-i H dt) psi.  The first application H(eps_new) psi = b + sum de_l a_l
         //      is already known, so sub-step 0 costs m-1 matvecs:
         //      psi' = psi + y1,  y_m = v,  y_{j-1} = v + (-i fs / j) H y_j,  v = -i fs (H psi)
         const double fs = (s == 1) ? dt : dt / (double)s;
@@ -593,7 +640,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
             for (int q = 0; q < KT; ++q) {
                 double wr = a0r[q], wi = a0i[q];
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l) { wr = fma(e[l], alr[q][l], wr); wi = fma(e[l], ali[q][l], wi); }
+                for (int l = 0; l < LMAX; ++l) { wr = fma(de[l], alr[q][l], wr); wi = fma(de[l], ali[q][l], wi); }
                 vr[q] = fs * wi;   // -i (wr + i wi) = wi - i wr
                 vi[q] = -fs * wr;
                 if (m > 1 && writer) sy[0][q * SG + team][pi_] = make_double2(vr[q], vi[q]);

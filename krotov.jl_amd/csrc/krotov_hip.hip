@@ -182,22 +182,32 @@ __global__ void kr_chi_kernel(int functional, const double2 *tgt, const double2 
 // ---- plan -------------------------------------------------------------------------------------
 static int make_plan(kr_handle *h) {
     const kr_config &c = h->cfg;
-    if (c.N > 64) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 64: the streamed-generator kernel is not built yet", c.N);
-    if (c.L > KR_LMAX_CAP) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > %d controls not supported by the register-resident kernels", c.L, KR_LMAX_CAP);
+    if (c.N > 256) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 256 is not supported by this build", c.N);
+    if (c.L > KR_LMAX_CAP) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > %d controls not supported by this build", c.L, KR_LMAX_CAP);
     int NP = 8;
     while (NP < c.N) NP <<= 1;
     h->NP = NP;
-    h->JQ = (NP >= 64) ? 8 : 4;
-    h->threads = (NP >= 64) ? 512 : 256;
+    h->LMAXv = (c.L <= 2) ? 2 : 4;
+    if (NP > 64) {
+        // streamed-generator kernels (kr_device_stream.h): one team of 4*NP threads per workgroup
+        h->threads = 4 * NP;
+        h->JQ = 4;
+    } else {
+        // mirrors KrGeom (kr_device.h): NP = 64 with L <= 2 keeps H0 in LDS and 256-thread teams, L > 2 uses 512
+        const bool h0lds = (NP >= 64) && (h->LMAXv <= 2);
+        h->threads = (NP >= 64 && !h0lds) ? 512 : 256;
+        h->JQ = (h->threads == 512) ? 8 : 4;
+    }
     h->JS = NP / h->JQ;
     h->RT = NP * h->JQ;
     h->SG = h->threads / h->RT;
-    h->LMAXv = (c.L <= 2) ? 2 : 4;
     switch (NP) {
         case 8: h->launch = kr_launch_np8; break;
         case 16: h->launch = kr_launch_np16; break;
         case 32: h->launch = kr_launch_np32; break;
-        default: h->launch = kr_launch_np64; break;
+        case 64: h->launch = kr_launch_np64; break;
+        case 128: h->launch = kr_launch_np128; break;
+        default: h->launch = kr_launch_np256; break;
     }
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, h->device));

@@ -228,3 +228,20 @@ def test_full_size_properties_c3():
             J.append(wl.chi_and_JT("ss", psiT, p["tgt"])[1])
             assert np.max(np.abs(np.linalg.norm(psiT, axis=1) - 1.0)) < 1e-12
         assert J[3] < J[2] < J[1] < J[0]
+
+
+def test_streamed_generator_sizes(oracle_c):
+    """64 < N <= 256: the streamed-generator kernels (kr_device_stream.h), Hermitian and Liouvillian."""
+    for (N, NT, K, L, seed) in [(65, 6, 2, 1, 41), (100, 5, 3, 2, 42), (128, 4, 2, 1, 43), (200, 3, 2, 3, 44)]:
+        p = wl.dense_problem(N, NT, K, L, seed, 0.05, 2.0)
+        info = _run_case(oracle_c, p)
+        assert info["NP"] in (128, 256)
+    p = wl.liouvillian_problem(n_levels=16, NT=4, K=3, seed=256001)   # C5's operators, short grid
+    info = _run_case(oracle_c, p)
+    assert info["NP"] == 256
+
+
+def test_unsupported_sizes_fail_loudly():
+    with pytest.raises(kr.KrotovHipError) as ei:
+        kr.HipEngine(np.eye(300), np.eye(300)[None], np.linspace(0, 1, 3), 1)
+    assert ei.value.code == kr._capi.KR_ERR_UNSUPPORTED
