@@ -28,6 +28,7 @@ struct KrSweepArgs {
     unsigned long long *mail;  // [2][P][2*LMAX] granules {tag32 | half of a double}
     unsigned long long *xmail; // [2][world][2*LMAX] inter-GPU granules (local memory, peers write)
     unsigned long long *peer_xmail[8]; // every rank's xmail (peer_xmail[rank] == xmail)
+    double2 *U;              // [NT][NP*NP] precomputed step propagators, thread-major (kr_device_prop.h), or nullptr
     unsigned *status;        // [KR_STATUS_WORDS]
     unsigned long long *debug; // nullptr, or [8]: workgroup 0's cycle counts per phase (diagnostics only)
     double nrm[1 + KR_LMAX_CAP]; // 2-norm bounds of H0, H_1..H_L
@@ -82,7 +83,8 @@ __device__ __forceinline__ void kr_plan_fast(const KrSweepArgs &a, const double 
 
 typedef hipError_t (*kr_launch_fn)(int variant_lmax, int variant_kt, int kind, int grid,
                                    hipStream_t stream, const KrSweepArgs *args);
-// kind: 0 = known-pulse sweep (forward or backward), 1 = update sweep
+// kind: 0 = known-pulse sweep (Taylor), 1 = update sweep, 2 = batched propagator build (grid = NT),
+//       3 = known-pulse sweep with precomputed propagators
 hipError_t kr_launch_np8(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np16(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np32(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);

@@ -30,7 +30,11 @@ struct KrGeom {
     // slice H0 lives in LDS (64 KB, read once per step when H(eps) is formed) and the team stays at 256
     // threads = one wave per SIMD (fewest non-FMA instructions per matvec round); for L > 2 the team is
     // widened to 512 threads (2 waves/SIMD, JQ = 8) so that 1+L+1 slices fit the register file.
+#ifdef KR_NO_H0LDS
+    static constexpr bool H0LDS = false;
+#else
     static constexpr bool H0LDS = (NP >= 64) && (LMAX <= 2);
+#endif
     static constexpr int THREADS = (NP >= 64 && !H0LDS) ? 512 : 256;
     static constexpr int JQ = (THREADS == 512) ? 8 : 4;  // lanes that share one row
     static constexpr int NW = THREADS / 64;
@@ -734,12 +738,16 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 }
 
 // ---- launcher table for one NP ---------------------------------------------------------------
+#include "kr_device_prop.h"
 template <int NP>
 static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
+    constexpr int CB = (NP >= 16) ? 4 : 1;
 #define KR_CASE(LM, KTv)                                                                          \
     if (lmax == LM && kt == KTv) {                                                                \
         if (kind == 0) hipLaunchKernelGGL((kr_sweep_known<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a);          \
+        else if (kind == 1) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        else if (kind == 2) hipLaunchKernelGGL((kr_expm_batch<NP, LM, CB>), dim3(grid), dim3(KrGeom<NP, LM, 1>::THREADS), 0, s, *a); \
+        else hipLaunchKernelGGL((kr_sweep_apply<NP, KTv>), dim3(grid), dim3(256), 0, s, *a);      \
         return hipGetLastError();                                                                 \
     }
     KR_CASE(2, 1) KR_CASE(2, 2) KR_CASE(2, 4)

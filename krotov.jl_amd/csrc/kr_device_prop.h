@@ -1,0 +1,195 @@
+// Precomputed step propagators for the two KNOWN-pulse sweeps (initial forward sweep, backward sweep).
+//
+// When the pulses of a sweep are known in advance (optimize.jl:247-265 and :303-317) all N_T step
+// propagators are independent of each other: kr_expm_batch builds them in parallel (one workgroup per time
+// step; the columns of U_n = exp(-i H(eps_n) dt) are the unit vectors pushed through the same Horner/Taylor
+// rounds the sweeps use, so accuracy and sub-stepping rules are identical), and kr_sweep_apply then needs
+// ONE matvec round per step instead of m ~ 9.  The update sweep cannot use this: eps_n is only known after
+// the global sum of step n (optimize.jl:339-361).
+//
+// U_n is stored thread-major for the apply kernel's 4*NP-thread teams:
+//   Upack[n][jj * 4NP + i*4 + jq] = U_n[i][jq*(NP/4) + jj]            (16 B per element)
+#pragma once
+// (included at the end of kr_device.h)
+
+// ---- batched propagator construction -------------------------------------------------------------
+template <int NP, int LMAX, int CB>
+__global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1>::THREADS / 256)) void kr_expm_batch(const KrSweepArgs a) {
+    double2 *__restrict__ Upack = a.U;
+    using G = KrGeom<NP, LMAX, 1>;
+    constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, NPP = G::NPP;
+    constexpr int JS_A = NP / 4, RT_A = 4 * NP;  // geometry of the consumer (kr_sweep_apply)
+    __shared__ __attribute__((aligned(16))) double2 sy[2][SG * CB][NPP];
+    __shared__ __attribute__((aligned(16))) double2 sH0[G::H0LDS ? JS * RT : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
+    const bool writer = (jq == 0);
+    const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
+    const int pi_ = i + i / JS, xoff = jq * (JS + 1);
+    const int NT = a.NT, L = a.L;
+    const int n = blockIdx.x;
+    const double sdt = (a.dir > 0) ? a.dt[n] : -a.dt[n];
+
+    double e[LMAX];
+    double theta = a.nrm[0];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        e[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0;
+        theta += fabs(e[l]) * a.nrm[1 + l];
+    }
+    theta *= fabs(sdt);
+    int s, m;
+    kr_plan_fast(a, theta, s, m);
+    const double fs = (s == 1) ? sdt : sdt / (double)s;
+
+    // H(eps_n) slice of this thread
+    double Er[JS], Ei[JS];
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj) {
+        const double2 h0 = a.Hpack[((size_t)0 * JS + jj) * RT + tt];
+        double r = h0.x, im = h0.y;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < L) {
+                const double2 hl = a.Hpack[((size_t)(1 + l) * JS + jj) * RT + tt];
+                r = fma(e[l], hl.x, r);
+                im = fma(e[l], hl.y, im);
+            }
+        }
+        Er[jj] = r;
+        Ei[jj] = im;
+    }
+    (void)sH0;
+
+    double2 *Un = Upack + (size_t)n * NP * NP;
+    // columns c = (chunk * SG + team) * CB + b ; every team runs the same number of rounds (uniform barriers)
+    for (int c0 = 0; c0 < NP; c0 += SG * CB) {
+        const int cbase = c0 + team * CB;
+        double pr[CB], pim[CB];
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+            pr[b] = (i == cbase + b) ? 1.0 : 0.0;  // unit vector e_c
+            pim[b] = 0.0;
+            if (writer) sy[0][team * CB + b][pi_] = make_double2(pr[b], 0.0);
+        }
+        __syncthreads();
+        int w = 1;  // sy[0] holds the current state
+        for (int sub = 0; sub < s; ++sub) {
+            for (int j = m; j >= 1; --j) {
+                const double f = fs * kr_rinv_lane(my_rinv, j);
+#pragma unroll
+                for (int b = 0; b < CB; ++b) {
+                    const int tq = team * CB + b;
+                    double sr, si;
+                    kr_row_dot<JS, JQ>(Er, Ei, &sy[w ^ 1][tq][xoff], sr, si);
+                    const double yr = fma(f, si, pr[b]);
+                    const double yi = fma(-f, sr, pim[b]);
+                    if (j == 1) { pr[b] = yr; pim[b] = yi; }
+                    if (writer) sy[w][tq][pi_] = make_double2(yr, yi);
+                }
+                __syncthreads();
+                w ^= 1;
+            }
+        }
+        if (writer) {
+#pragma unroll
+            for (int b = 0; b < CB; ++b) {
+                const int c = cbase + b;
+                if (c < NP) Un[(size_t)(c % JS_A) * RT_A + i * 4 + (c / JS_A)] = make_double2(pr[b], pim[b]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- known-pulse sweep with precomputed propagators: one round per step ---------------------------
+template <int NP, int KT>
+__global__ __launch_bounds__(256, 1) void kr_sweep_apply(const KrSweepArgs a) {
+    const double2 *__restrict__ Upack = a.U;
+    constexpr int JQ = 4, JS = NP / 4, RT = 4 * NP, SG = 256 / RT, KTILE = SG * KT, NPP = NP + JQ, NW = 4;
+    constexpr int CH = (KTILE * NP + 63) / 64;
+    __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];
+
+    const int tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
+    const bool writer = (jq == 0), row_ok = (i < a.N);
+    const bool memwave = (wave == NW - 1);
+    const int pi_ = i + i / JS, xoff = jq * (JS + 1);
+    const int N = a.N, NT = a.NT;
+    const size_t slab = (size_t)a.Kp * N;
+    const size_t tile_base = (size_t)wg * KTILE * N;
+    const int tile_elems = KTILE * N;
+
+    int m_tq[CH], m_i[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int e = lane + 64 * c;
+        m_tq[c] = (e < tile_elems) ? e / N : -1;
+        m_i[c] = (e < tile_elems) ? e % N : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+        const int tq = q * SG + team;
+        double2 v = make_double2(0.0, 0.0);
+        if (row_ok) v = a.init[tile_base + (size_t)tq * N + i];
+        if (writer) sx[0][tq][pi_] = v;
+    }
+    if (memwave && a.store) {
+        const int slot0 = (a.dir > 0) ? 0 : NT;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (m_tq[c] >= 0) a.store[(size_t)slot0 * slab + tile_base + lane + 64 * c] = a.init[tile_base + lane + 64 * c];
+    }
+    // propagator slice of the first step
+    double2 un[JS];
+    {
+        const int n0 = (a.dir > 0) ? 0 : (NT - 1);
+        const double2 *U = Upack + (size_t)n0 * NP * NP;
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) un[jj] = U[(size_t)jj * RT + tt];
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = 0; step < NT; ++step) {
+        const int n = (a.dir > 0) ? step : (NT - 1 - step);
+        double Ur[JS], Ui[JS];
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) { Ur[jj] = un[jj].x; Ui[jj] = un[jj].y; }
+        if (step + 1 < NT) {  // slice of the next step: lands while this step's round runs
+            const int n1 = (a.dir > 0) ? (step + 1) : (NT - 2 - step);
+            const double2 *U = Upack + (size_t)n1 * NP * NP;
+#pragma unroll
+            for (int jj = 0; jj < JS; ++jj) un[jj] = U[(size_t)jj * RT + tt];
+        }
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+            const int tq = q * SG + team;
+            double sr, si;
+            kr_row_dot<JS, JQ>(Ur, Ui, &sx[cur][tq][xoff], sr, si);
+            if (writer) sx[cur ^ 1][tq][pi_] = make_double2(sr, si);
+        }
+        __syncthreads();
+        cur ^= 1;
+        if (memwave && a.store) {
+            const int slot = (a.dir > 0) ? (n + 1) : n;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (m_tq[c] >= 0) {
+                    const int ii = m_i[c];
+                    a.store[(size_t)slot * slab + tile_base + lane + 64 * c] = sx[cur][m_tq[c]][ii + ii / JS];
+                }
+            }
+        }
+    }
+    if (a.fin && memwave) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (m_tq[c] >= 0) {
+                const int ii = m_i[c];
+                a.fin[tile_base + lane + 64 * c] = sx[cur][m_tq[c]][ii + ii / JS];
+            }
+        }
+    }
+}

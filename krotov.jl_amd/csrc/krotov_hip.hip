@@ -45,6 +45,8 @@ struct kr_handle {
     double *dt_d = nullptr, *eps_a = nullptr, *eps_b = nullptr, *S_d = nullptr, *lambda_d = nullptr, *gint_d = nullptr;
     double2 *psi0_d = nullptr, *tgt_d = nullptr, *psiT_d = nullptr, *chiT_d = nullptr, *X_d = nullptr, *Phi_d = nullptr;
     double2 *tau_d = nullptr, *tausum_d = nullptr;
+    double2 *U_d = nullptr;   // precomputed step propagators of the known-pulse sweeps (N <= 64), or nullptr
+    bool precomp = false;
     unsigned long long *mail_d = nullptr, *xmail_d = nullptr;
     unsigned long long *peer_xmail[8]{};
     bool peers_connected = false;
@@ -96,7 +98,8 @@ static double norm2_bound(int n, const zc *A) {
     std::vector<zc> x(n), y(n), z(n);
     for (int i = 0; i < n; ++i) x[i] = zc(1.0 + 0.37 * std::sin(1.7 * i + 0.3), 0.21 * std::cos(2.3 * i));
     double sigma = 0;
-    for (int it = 0; it < 200; ++it) {
+    bool converged = false;
+    for (int it = 0; it < 2000; ++it) {
         double nx = 0;
         for (int i = 0; i < n; ++i) nx += std::norm(x[i]);
         nx = std::sqrt(nx);
@@ -113,11 +116,14 @@ static double norm2_bound(int n, const zc *A) {
             z[j] = acc;
         }
         x = z;
-        const bool done = (it > 8 && std::fabs(s_new - sigma) <= 1e-6 * s_new);
+        converged = (it > 20 && std::fabs(s_new - sigma) <= 1e-9 * s_new);
         sigma = s_new;
-        if (done) break;
+        if (converged) break;
     }
-    return std::min(cap, sigma * 1.05);
+    // power iteration approaches sigma_max from below: a small margin when it has converged, a larger one
+    // otherwise; never above the rigorous bound.  (The Taylor remainder bound moves by (1+d)^m for a relative
+    // error d of the norm, so the margin only has to cover the residual of the iteration.)
+    return std::min(cap, sigma * (converged ? 1.001 : 1.05));
 }
 
 // Pack generator m (column-major N x N) into the thread-major slice layout of the kernels:
@@ -194,7 +200,11 @@ static int make_plan(kr_handle *h) {
         h->JQ = 4;
     } else {
         // mirrors KrGeom (kr_device.h): NP = 64 with L <= 2 keeps H0 in LDS and 256-thread teams, L > 2 uses 512
+#ifdef KR_NO_H0LDS
+        const bool h0lds = false;
+#else
         const bool h0lds = (NP >= 64) && (h->LMAXv <= 2);
+#endif
         h->threads = (NP >= 64 && !h0lds) ? 512 : 256;
         h->JQ = (h->threads == 512) ? 8 : 4;
     }
@@ -235,7 +245,7 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
-                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d};
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -347,6 +357,13 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     CHK(dalloc(&h->chiT_d, slab));
     CHK(dalloc(&h->X_d, slab * (NT + 1)));
     if (h->store_fw) CHK(dalloc(&h->Phi_d, slab * (NT + 1)));
+    // Known-pulse sweeps with precomputed propagators (kr_device_prop.h): N <= 64, and the U buffer
+    // (NT * NP^2 * 16 B) within a budget; KROTOV_HIP_PRECOMP=0 keeps the Taylor sweeps.
+    {
+        const size_t ubytes = (size_t)NT * NP * NP * sizeof(double2);
+        h->precomp = (NP <= 64) && env_int("KROTOV_HIP_PRECOMP", 1) != 0 && ubytes <= ((size_t)8 << 30);
+        if (h->precomp) CHK(dalloc(&h->U_d, (size_t)NT * NP * NP));
+    }
     CHK(dalloc(&h->tau_d, h->Kp));
     CHK(dalloc(&h->tausum_d, 1));
     CHK(hipMemset(h->psi0_d, 0, slab * sizeof(double2)));
@@ -426,7 +443,7 @@ extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
     if (!h || !info) return KR_ERR_INVALID;
     memset(info, 0, 16 * sizeof(int32_t));
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
-    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ;
+    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0;
     // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
     return KR_OK;
 }
@@ -491,9 +508,16 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     a.eps = eps_dev;
     a.init = init; a.store = store; a.fin = fin;
     a.dir = backward ? -1 : +1;
+    a.U = h->U_d;
     int rc = ev_mark(h, which_ev, false);
     if (rc) return rc;
-    HIPCHK(h, h->launch(h->LMAXv, h->KT, 0, h->P, h->stream, &a));
+    if (h->precomp) {
+        // all N_T step propagators in parallel, then one matvec round per step
+        HIPCHK(h, h->launch(h->LMAXv, h->KT, 2, h->cfg.NT, h->stream, &a));
+        HIPCHK(h, h->launch(h->LMAXv, h->KT, 3, h->P, h->stream, &a));
+    } else {
+        HIPCHK(h, h->launch(h->LMAXv, h->KT, 0, h->P, h->stream, &a));
+    }
     return ev_mark(h, which_ev, true);
 }
 
