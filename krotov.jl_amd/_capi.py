@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkrotov_hip.so")
+LIB_PATH = os.environ.get("KROTOV_HIP_LIB", os.path.join(_HERE, "lib", "libkrotov_hip.so"))  # env: A/B builds
 
 KR_ABI_VERSION = 1
 KR_OK, KR_ERR_INVALID, KR_ERR_NO_DEVICE, KR_ERR_HIP, KR_ERR_UNSUPPORTED, KR_ERR_TIMEOUT, KR_ERR_STATE = range(7)

@@ -69,13 +69,19 @@ __device__ __constant__ static const double kr_rinv[KR_MAX_ORDER + 1] = {
     1.0 / 35, 1.0 / 36, 1.0 / 37, 1.0 / 38, 1.0 / 39, 1.0 / 40, 1.0 / 41, 1.0 / 42, 1.0 / 43, 1.0 / 44, 1.0 / 45,
     1.0 / 46, 1.0 / 47, 1.0 / 48};
 
-// Device-side plan: table lookup for the common single-sub-step case (no fp64 divisions on the
-// critical path), the general routine otherwise.
-__device__ __forceinline__ void kr_plan_fast(const KrSweepArgs &a, const double theta, int &s, int &m) {
+// Device-side plan without memory accesses on the critical path: lane k of every wave keeps thr[k] in a
+// register (`my_thr`, loaded once at kernel start); for a wave-uniform theta the order is one compare, one
+// ballot and a popcount:  m = 1 + #{1 <= k : theta > thr[k]}  (thr is increasing in k).
+__device__ __forceinline__ double kr_load_my_thr(const KrSweepArgs &a) {
+    const int lane = threadIdx.x & 63;
+    return a.thr[lane < KR_MAX_ORDER ? lane : KR_MAX_ORDER - 1];
+}
+__device__ __forceinline__ void kr_plan_fast(const KrSweepArgs &a, const double my_thr, const double theta, int &s, int &m) {
     if (theta <= KR_THETA_MAX) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long above = __ballot(lane >= 1 && lane < KR_MAX_ORDER - 1 && theta > my_thr);
         s = 1;
-        m = 1;
-        while (m < KR_MAX_ORDER - 1 && theta > a.thr[m]) ++m;
+        m = 1 + __popcll(above);
     } else {
         kr_taylor_plan(theta, a.tol, s, m);
     }

@@ -26,16 +26,16 @@
 
 template <int NP, int LMAX, int KT>
 struct KrGeom {
-    // NP = 64: the four slices H0, H1, H2, H(eps) of a 256-thread team need 256 VGPRs.  For L <= 2 the drift
-    // slice H0 lives in LDS (64 KB, read once per step when H(eps) is formed) and the team stays at 256
-    // threads = one wave per SIMD (fewest non-FMA instructions per matvec round); for L > 2 the team is
-    // widened to 512 threads (2 waves/SIMD, JQ = 8) so that 1+L+1 slices fit the register file.
+    // NP = 64: 512-thread teams (2 waves/SIMD, JQ = 8: measured 795 vs 966 cycles per matvec round against
+    // 256 threads, tools/ubench/round.hip).  For L <= 2 the drift slice H0 additionally lives in LDS (64 KB,
+    // read once per step when H(eps) is formed) so that the register file keeps room for all LDS reads of a
+    // round in flight; for L > 2 all 1+L+1 slices stay in registers.
 #ifdef KR_NO_H0LDS
     static constexpr bool H0LDS = false;
 #else
     static constexpr bool H0LDS = (NP >= 64) && (LMAX <= 2);
 #endif
-    static constexpr int THREADS = (NP >= 64 && !H0LDS) ? 512 : 256;
+    static constexpr int THREADS = (NP >= 64) ? 512 : 256;
     static constexpr int JQ = (THREADS == 512) ? 8 : 4;  // lanes that share one row
     static constexpr int NW = THREADS / 64;
     static constexpr int JS = NP / JQ;
@@ -146,6 +146,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const double my_rinv = kr_rinv[(tid & 63) <= KR_MAX_ORDER ? (tid & 63) : 0];
+    const double my_thr = kr_load_my_thr(a);
     const int pi_ = i + i / JS;          // padded position of element i
     const int xoff = jq * (JS + 1);      // padded start of this thread's column segment
     const int N = a.N, NT = a.NT, L = a.L;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
             for (int l = 0; l < LMAX; ++l) if (l < L) e_nx[l] = a.eps[(size_t)l * NT + n1];
         }
         int s, m;
-        kr_plan_fast(a, theta, s, m);
+        kr_plan_fast(a, my_thr, theta, s, m);
 
         double Er[JS], Ei[JS];
 #pragma unroll
@@ -283,6 +284,12 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 // front of the poll would otherwise sit on the critical path of every step.
 // Returns false when the exchange was aborted (status[0] set).
 // =============================================================================================
+// Mailbox slot = 2*LMAX granules, packed (32 B for LMAX = 2).  Measured at P = 256 (C3): 32-B slots 8.0k cycles
+// per exchange, 64-B 8.45k, 128-B 10.2k, granule-major (SoA, 16 writers per line) 10.3k: the cost grows with
+// the number of 128-B lines a poll pass touches and with the number of workgroups writing one line.
+#ifndef KR_SLOT_GRANULES
+#define KR_SLOT_GRANULES (2 * LMAX)
+#endif
 #define KR_POLL_CHUNKS 4  // slots per lane gathered with all loads in flight at once (P <= 256 in one go)
 template <int LMAX, int ROWS>
 __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg, const bool writer,
@@ -315,7 +322,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         }
         if (!(P == 1 && a.world == 1)) {
             // 2. publish this workgroup's partial
-            kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)par * P + wg) * (2 * LMAX));
+            kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)par * P + wg) * KR_SLOT_GRANULES);
             if (lane < 2 * L) {
                 double v = 0.0;
 #pragma unroll
@@ -339,7 +346,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                     for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
                         if (q0 + 64 * c < P) {  // wave-uniform
                             const int q = min(q0 + 64 * c + lane, P - 1);
-                            kr_gu64 *sq = (kr_gu64 *)(a.mail + ((size_t)par * P + q) * (2 * LMAX));
+                            kr_gu64 *sq = (kr_gu64 *)(a.mail + ((size_t)par * P + q) * KR_SLOT_GRANULES);
 #pragma unroll
                             for (int w = 0; w < 2 * LMAX; ++w)
                                 g[c][w] = __hip_atomic_load(sq + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -468,6 +475,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const bool memwave = (wave == NW - 1);
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
+    const double my_thr = kr_load_my_thr(a);
     const int rowid = tid / JQ;  // 0..63
     const int pi_ = i + i / JS;
     const int xoff = jq * (JS + 1);
@@ -531,7 +539,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 
     // optional phase stamps of workgroup 0 (diagnostic runs only; a.debug == nullptr otherwise)
     const bool stamp = (a.debug != nullptr) && (wg == 0);
-    unsigned long long tA = 0, tX = 0, tB = 0, tS = 0, t_prev = 0, rt0 = 0;
+    unsigned long long tA = 0, tX = 0, tB = 0, tS = 0, tB1 = 0, tB2 = 0, t_prev = 0, rt0 = 0;
     if (stamp) { t_prev = __builtin_amdgcn_s_memtime(); rt0 = kr_realtime(); }
     int cur = 0;
     // guess pulse, step size alpha = S/lambda and dt of the NEXT step are fetched one step ahead
@@ -622,7 +630,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         }
         theta *= fabs(dt);
         int s, m;
-        kr_plan_fast(a, theta, s, m);
+        kr_plan_fast(a, my_thr, theta, s, m);
 
         // H(eps_new) = H(eps_guess) + sum_l (eps_new - eps_guess)_l H_l   (H(eps_guess) was formed before phase A)
 #pragma unroll
@@ -650,6 +658,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 if (m > 1 && writer) sy[0][q * SG + team][pi_] = make_double2(vr[q], vi[q]);
             }
             if (m > 1) __syncthreads();
+            if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB1 += t - t_prev; }
             int w = 1;
             double yr[KT], yi[KT];
 #pragma unroll
@@ -668,6 +677,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 if (j > 2) __syncthreads();
                 w ^= 1;
             }
+            if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB2 += t - t_prev; }
 #pragma unroll
             for (int q = 0; q < KT; ++q) {
                 pr[q] += yr[q];
@@ -725,7 +735,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     }
     if (stamp && tid == 0) {
         a.debug[0] = tA; a.debug[1] = tX; a.debug[2] = tB; a.debug[3] = tS;
-        a.debug[4] = kr_realtime() - rt0;
+        a.debug[4] = kr_realtime() - rt0; a.debug[5] = tB1; a.debug[6] = tB2;
     }
     if (a.fin && writer && row_ok) {
 #pragma unroll

@@ -26,6 +26,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
     const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
     const bool writer = (jq == 0);
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
+    const double my_thr = kr_load_my_thr(a);
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int NT = a.NT, L = a.L;
     const int n = blockIdx.x;
@@ -40,7 +41,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
     }
     theta *= fabs(sdt);
     int s, m;
-    kr_plan_fast(a, theta, s, m);
+    kr_plan_fast(a, my_thr, theta, s, m);
     const double fs = (s == 1) ? sdt : sdt / (double)s;
 
     // H(eps_n) slice of this thread

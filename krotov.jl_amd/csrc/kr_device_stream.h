@@ -88,6 +88,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
     const int tt = tid, i = tt / JQ, jq = tt % JQ;
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
+    const double my_thr = kr_load_my_thr(a);
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
         }
         theta *= fabs(sdt);
         int s, m;
-        kr_plan_fast(a, theta, s, m);
+        kr_plan_fast(a, my_thr, theta, s, m);
         const double fs = (s == 1) ? sdt : sdt / (double)s;
         for (int sub = 0; sub < s; ++sub) {
             int w = 0;
@@ -169,6 +170,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
     const int tt = tid, i = tt / JQ, jq = tt % JQ;
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
+    const double my_thr = kr_load_my_thr(a);
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
         }
         theta *= fabs(dt);
         int s, m;
-        kr_plan_fast(a, theta, s, m);
+        kr_plan_fast(a, my_thr, theta, s, m);
         const double fs = (s == 1) ? dt : dt / (double)s;
         {
             double vr[KT], vi[KT], yr[KT], yi[KT];

@@ -199,13 +199,8 @@ static int make_plan(kr_handle *h) {
         h->threads = 4 * NP;
         h->JQ = 4;
     } else {
-        // mirrors KrGeom (kr_device.h): NP = 64 with L <= 2 keeps H0 in LDS and 256-thread teams, L > 2 uses 512
-#ifdef KR_NO_H0LDS
-        const bool h0lds = false;
-#else
-        const bool h0lds = (NP >= 64) && (h->LMAXv <= 2);
-#endif
-        h->threads = (NP >= 64 && !h0lds) ? 512 : 256;
+        // mirrors KrGeom (kr_device.h): NP = 64 uses 512-thread teams (JQ = 8)
+        h->threads = (NP >= 64) ? 512 : 256;
         h->JQ = (h->threads == 512) ? 8 : 4;
     }
     h->JS = NP / h->JQ;
@@ -371,7 +366,7 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     CHK(hipMemset(h->psiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->chiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->gint_d, 0, KR_LMAX_CAP * sizeof(double)));
-    const size_t mail_words = (size_t)2 * h->P * 2 * KR_LMAX_CAP;
+    const size_t mail_words = (size_t)2 * h->P * 16;  // up to 128-B slots (KR_SLOT_GRANULES <= 16)
     CHK(dalloc(&h->mail_d, mail_words));
     CHK(hipMemset(h->mail_d, 0, mail_words * sizeof(unsigned long long)));
     CHK(dalloc(&h->debug_d, 8));

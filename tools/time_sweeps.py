@@ -36,6 +36,6 @@ if st[4]:
     cyc = sum(st[:4]); us = st[4] / 100.0
     print("  stamps (wg 0): matvec+dot %.0f  exchange %.0f  taylor %.0f  store %.0f cycles/step; clock %.2f GHz; %.2f us/step"
           % (st[0] / NT, st[1] / NT, st[2] / NT, st[3] / NT, cyc / us / 1e3, us / NT))
-if st[7]:
-    print("  known-sweep rounds (wg 0): %.0f cycles to row sums (LDS read + FMA + DPP), %.0f cycles write+barrier, %d rounds"
-          % (st[5] / st[7], st[6] / st[7], st[7]))
+if st[5]:
+    print("  taylor phase split (wg 0): setup until first round %.0f, rounds %.0f, finalize %.0f cycles/step"
+          % (st[5] / NT, (st[6] - st[5]) / NT, (st[2] - st[6]) / NT))

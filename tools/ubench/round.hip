@@ -11,15 +11,15 @@ __device__ __forceinline__ double dppmov(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int JS, int VAR>
-__global__ __launch_bounds__(256, 1) void round_kernel(double *out, unsigned long long *cyc, int iters) {
-    constexpr int NP = 4 * JS;           // JQ = 4
-    constexpr int NPP = NP + 4;
-    constexpr int RT = NP * 4, SG = 256 / RT;
+template <int JS, int VAR, int JQ = 4, int THREADS = 256>
+__global__ __launch_bounds__(THREADS, THREADS / 256) void round_kernel(double *out, unsigned long long *cyc, int iters) {
+    constexpr int NP = JQ * JS;
+    constexpr int NPP = NP + JQ;
+    constexpr int RT = NP * JQ, SG = THREADS / RT;
     __shared__ __attribute__((aligned(16))) double2 sy[2][SG][NPP];
     __shared__ __attribute__((aligned(16))) double2 sbig[VAR == 6 ? 64 * JS : 1];
     if (VAR == 6) for (int e = threadIdx.x; e < 64 * JS; e += 256) sbig[e] = make_double2(1e-3 * e, 0.1);
-    const int tid = threadIdx.x, team = tid / RT, tt = tid % RT, i = tt >> 2, jq = tt & 3;
+    const int tid = threadIdx.x, team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     double Er[JS], Ei[JS];
 #pragma unroll
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 1) void round_kernel(double *out, unsigned lon
 #pragma unroll
             for (int jj = 0; jj < JS; ++jj) x[jj] = make_double2(x0.x + jj, x0.y - jj);
         } else if (VAR == 6) {  // VAR 6: same reads but every lane its own address (no broadcast), conflict-free
-            const double2 *xq = &sbig[(tid & 63) + 64 * (tid >> 6) * 0];
+            const double2 *xq = &sbig[(tid & 63)];
 #pragma unroll
             for (int jj = 0; jj < JS; ++jj) x[jj] = xq[jj * 64];
         } else {
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256, 1) void round_kernel(double *out, unsigned lon
         if (VAR != 1) {  // VAR 1: no DPP reduction
             sr += dppmov<0xB1>(sr); si += dppmov<0xB1>(si);
             sr += dppmov<0x4E>(sr); si += dppmov<0x4E>(si);
+            if (JQ == 8) { sr += dppmov<0x141>(sr); si += dppmov<0x141>(si); }
         }
         const double yr = fma(1e-3, si, pr), yi = fma(-1e-3, sr, pim);
         if (VAR == 2) {  // VAR 2: every lane writes (no exec masking), to its own padded slot
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void round_kernel(double *out, unsigned lon
     }
     __syncthreads();
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x * 256 + tid] = pr + sy[0][team][pi_].x;
+    out[blockIdx.x * THREADS + tid] = pr + sy[0][team][pi_].x;
     if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
@@ -87,6 +88,11 @@ int main() {
     RUN(8, 0, "baseline") RUN(8, 1, "no DPP")
     RUN(16, 0, "baseline") RUN(16, 1, "no DPP") RUN(16, 2, "all lanes write") RUN(16, 3, "raw s_barrier")
     RUN(16, 4, "FMAs, 1 LDS read") RUN(16, 5, "16 LDS reads, adds only") RUN(16, 6, "non-broadcast reads")
+#define RUN2(JS, JQv, TH, label) \
+    hipLaunchKernelGGL((round_kernel<JS, 0, JQv, TH>), dim3(256), dim3(TH), 0, 0, out, cyc, iters); \
+    (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost); \
+    printf("JS=%2d JQ=%d threads=%d (NP=%2d) %-12s: %.1f cycles per round\n", JS, JQv, TH, JQv * JS, label, (double)h / iters);
+    RUN2(8, 8, 512, "512-thread") RUN2(4, 16, 1024, "1024-thread") RUN2(16, 4, 256, "256-thread")
     RUN(4, 4, "FMAs, 1 LDS read") RUN(4, 5, "4 LDS reads, adds only") RUN(4, 6, "non-broadcast reads")
     return 0;
 }
