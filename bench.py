@@ -173,6 +173,17 @@ def main():
         avg_upd = upd_ms / max(upd_n, 1)
         avg_bw = bw_ms / max(bw_n, 1)
         achieved = flops_upd / (avg_upd * 1e-3) / 1e12 if upd_n else None
+        # HBM bytes of the dominant kernel per launch from the committed PMC passes (tools/profile.sh on this very
+        # command; bench.py itself does not run under rocprofv3).  Only quoted for the configuration it was taken on.
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("config") == args.config and world == 1:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj["source"]
+        except (OSError, ValueError, KeyError):
+            pass
+        bytes_upd = K_local * NT * 32.0 * N
         line = {
             "metric": "Krotov iters/sec + state*timesteps/sec, N=64 nt=1000 K=256 traj",
             "value": value,
@@ -194,13 +205,18 @@ def main():
                        "engine": info},
             "roofline": {"bound": "mfma", "kernel": "kr_sweep_update", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": bytes_upd,
+                         "hbm_achieved_GBs": bytes_upd / (avg_upd * 1e-3) / 1e9 if upd_n else None, "hbm_peak_GBs": HBM_PEAK_GBS,
                          "avg_launch_ms": avg_upd, "launches": upd_n,
                          "algorithmic_flops_per_launch": flops_upd,
                          "backward_kernel": {"avg_launch_ms": avg_bw, "launches": bw_n,
                                              "achieved": (flops_bw / (avg_bw * 1e-3) / 1e12) if bw_n else None},
-                         "note": "fp64 VALU kernel (matrix peak = vector peak for fp64); sequential-latency bound: "
-                                 "N_T dependent steps with one global sum each"},
+                         "note": "fp64 VALU kernel (fp64 matrix peak = vector peak on MI355X); achieved counts ALGORITHMIC flops "
+                                 "(precomputed-propagator model, SURVEY 8d); the binding limit is sequential latency: N_T "
+                                 "dependent steps, each = (1+L) matvecs + one all-to-all sum over 256 workgroups + (m-1) "
+                                 "Taylor matvec rounds (m ~ 8)"},
             "J_T": {"before": float(J0), "after": float(J1)},
         }
         if not args.no_cpu_baseline and world == 1:
