@@ -13,8 +13,12 @@
 #define KR_STATUS_WORDS 4
 
 struct KrSweepArgs {
-    // generator slices, thread-major: Hpack[m][jj][tid_in_team] (double2), m = 0..L
+    // generator slices, thread-major: Hpack[g][m][jj][tid_in_team] (double2), g = generator, m = 0..L
     const double2 *Hpack;
+    size_t pack_stride;      // elements between two generators' packs
+    const int *wg_gen;       // [P] generator of each workgroup's tile (nullptr: all 0)
+    const double *nrm_dev;   // [G][1 + KR_LMAX_CAP] 2-norm bounds of H0, H_1..H_L per generator
+    const unsigned *present_dev; // [G] bit l set: control l has a derivative in generator g (optimize.jl:344)
     const double *eps;       // [L][NT] pulses that drive this sweep (known-pulse sweeps) / guess (update)
     const double *dt;        // [NT]
     const double2 *init;     // [Kp][N] initial states (psi0, or chi(T) for the backward sweep)
@@ -31,10 +35,8 @@ struct KrSweepArgs {
     double2 *U;              // [NT][NP*NP] precomputed step propagators, thread-major (kr_device_prop.h), or nullptr
     unsigned *status;        // [KR_STATUS_WORDS]
     unsigned long long *debug; // nullptr, or [8]: workgroup 0's cycle counts per phase (diagnostics only)
-    double nrm[1 + KR_LMAX_CAP]; // 2-norm bounds of H0, H_1..H_L
     double tol;
     double thr[KR_MAX_ORDER];    // thr[m] = largest theta <= KR_THETA_MAX for which Taylor order m meets tol
-    unsigned present_mask;   // bit l set: control l has a derivative (optimize.jl:344)
     int N, NT, Kp, L;
     int dir;                 // +1 forward (store slot n+1), -1 backward (store slot n)
     int P;                   // workgroups
@@ -59,6 +61,25 @@ __host__ __device__ inline void kr_taylor_plan(double theta, double tol, int &s,
         if (rem <= budget) break;
         term = next;
     }
+}
+
+// Per-workgroup generator context (per-trajectory generators: control_derivs[k][l], workspace.jl:74)
+template <int LMAX>
+struct KrGen {
+    const double2 *Hpack;
+    double nrm[1 + LMAX];
+    unsigned present;
+    int gen;
+};
+template <int LMAX>
+__device__ __forceinline__ KrGen<LMAX> kr_gen_ctx(const KrSweepArgs &a, const int gen) {
+    KrGen<LMAX> g;
+    g.gen = gen;
+    g.Hpack = a.Hpack + (size_t)gen * a.pack_stride;
+#pragma unroll
+    for (int m = 0; m <= LMAX; ++m) g.nrm[m] = a.nrm_dev[(size_t)gen * (1 + KR_LMAX_CAP) + m];
+    g.present = a.present_dev[gen];
+    return g;
 }
 
 // 1/j, j = 0..KR_MAX_ORDER (index 0 unused): the Horner coefficients without an fp64 division

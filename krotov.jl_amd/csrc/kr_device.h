@@ -147,6 +147,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const double my_rinv = kr_rinv[(tid & 63) <= KR_MAX_ORDER ? (tid & 63) : 0];
     const double my_thr = kr_load_my_thr(a);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x] : 0);
     const int pi_ = i + i / JS;          // padded position of element i
     const int xoff = jq * (JS + 1);      // padded start of this thread's column segment
     const int N = a.N, NT = a.NT, L = a.L;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
         for (int jj = 0; jj < JS; ++jj) {
             double2 h = make_double2(0.0, 0.0);
-            if (m <= L) h = a.Hpack[((size_t)m * JS + jj) * RT + tt];
+            if (m <= L) h = gx.Hpack[((size_t)m * JS + jj) * RT + tt];
             if (G::H0LDS && m == 0) {
                 sH0[jj * RT + tt] = h;
                 Hr[m][jj] = 0.0; Hi[m][jj] = 0.0;  // dead: never read when H0LDS
@@ -200,11 +201,11 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         const int n = (a.dir > 0) ? step : (NT - 1 - step);
         const double sdt = (a.dir > 0) ? dt_nx : -dt_nx;
         double e[LMAX];
-        double theta = a.nrm[0];
+        double theta = gx.nrm[0];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             e[l] = e_nx[l];
-            if (l < L) theta += fabs(e[l]) * a.nrm[1 + l];
+            if (l < L) theta += fabs(e[l]) * gx.nrm[1 + l];
         }
         theta *= fabs(sdt);
         if (step + 1 < NT) {
@@ -476,6 +477,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     const bool memwave = (wave == NW - 1);
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
     const double my_thr = kr_load_my_thr(a);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x] : 0);
     const int rowid = tid / JQ;  // 0..63
     const int pi_ = i + i / JS;
     const int xoff = jq * (JS + 1);
@@ -491,7 +493,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
         for (int jj = 0; jj < JS; ++jj) {
             double2 h = make_double2(0.0, 0.0);
-            if (m <= L) h = a.Hpack[((size_t)m * JS + jj) * RT + tt];
+            if (m <= L) h = gx.Hpack[((size_t)m * JS + jj) * RT + tt];
             if (G::H0LDS && m == 0) {
                 sH0[jj * RT + tt] = h;
                 Hr[m][jj] = 0.0; Hi[m][jj] = 0.0;  // dead: never read when H0LDS
@@ -593,7 +595,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 if (l < L) {
                     kr_row_dot<JS, JQ>(Hr[1 + l], Hi[1 + l], src, alr[q][l], ali[q][l]);
                     // Im(conj(chi) * a) = chi_r a_i - chi_i a_r ; one lane per row contributes
-                    if ((a.present_mask >> l) & 1u) part[l] += chi.x * ali[q][l] - chi.y * alr[q][l];
+                    if ((gx.present >> l) & 1u) part[l] += chi.x * ali[q][l] - chi.y * alr[q][l];
                 }
             }
         }
@@ -613,7 +615,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 
         // ---- pulse update (optimize.jl:351-358), identical on every workgroup ---------------
         double e[LMAX], de[LMAX];
-        double theta = a.nrm[0];
+        double theta = gx.nrm[0];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             e[l] = 0.0; de[l] = 0.0;
@@ -624,7 +626,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 de[l] = e[l] - eg[l];  // what H(eps_guess) has to be corrected by (== deps up to rounding)
                 const double ad = fabs(du[l]);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dt));
-                theta += fabs(e[l]) * a.nrm[1 + l];
+                theta += fabs(e[l]) * gx.nrm[1 + l];
                 if (wg == 0 && memwave && lane == 0) a.eps_new[(size_t)l * NT + n] = e[l];
             }
         }

@@ -27,17 +27,18 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
     const bool writer = (jq == 0);
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
     const double my_thr = kr_load_my_thr(a);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, blockIdx.x / a.NT);
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int NT = a.NT, L = a.L;
-    const int n = blockIdx.x;
+    const int n = blockIdx.x % a.NT;
     const double sdt = (a.dir > 0) ? a.dt[n] : -a.dt[n];
 
     double e[LMAX];
-    double theta = a.nrm[0];
+    double theta = gx.nrm[0];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
         e[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0;
-        theta += fabs(e[l]) * a.nrm[1 + l];
+        theta += fabs(e[l]) * gx.nrm[1 + l];
     }
     theta *= fabs(sdt);
     int s, m;
@@ -48,12 +49,12 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
     double Er[JS], Ei[JS];
 #pragma unroll
     for (int jj = 0; jj < JS; ++jj) {
-        const double2 h0 = a.Hpack[((size_t)0 * JS + jj) * RT + tt];
+        const double2 h0 = gx.Hpack[((size_t)0 * JS + jj) * RT + tt];
         double r = h0.x, im = h0.y;
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             if (l < L) {
-                const double2 hl = a.Hpack[((size_t)(1 + l) * JS + jj) * RT + tt];
+                const double2 hl = gx.Hpack[((size_t)(1 + l) * JS + jj) * RT + tt];
                 r = fma(e[l], hl.x, r);
                 im = fma(e[l], hl.y, im);
             }
@@ -63,7 +64,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
     }
     (void)sH0;
 
-    double2 *Un = Upack + (size_t)n * NP * NP;
+    double2 *Un = Upack + ((size_t)gx.gen * NT + n) * NP * NP;
     // columns c = (chunk * SG + team) * CB + b ; every team runs the same number of rounds (uniform barriers)
     for (int c0 = 0; c0 < NP; c0 += SG * CB) {
         const int cbase = c0 + team * CB;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
 // ---- known-pulse sweep with precomputed propagators: one round per step ---------------------------
 template <int NP, int KT>
 __global__ __launch_bounds__(256, 1) void kr_sweep_apply(const KrSweepArgs a) {
-    const double2 *__restrict__ Upack = a.U;
+    const double2 *__restrict__ Upack = a.U + (size_t)(a.wg_gen ? a.wg_gen[blockIdx.x] : 0) * a.NT * NP * NP;
     constexpr int JQ = 4, JS = NP / 4, RT = 4 * NP, SG = 256 / RT, KTILE = SG * KT, NPP = NP + JQ, NW = 4;
     constexpr int CH = (KTILE * NP + 63) / 64;
     __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];

@@ -89,6 +89,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
     const double my_thr = kr_load_my_thr(a);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x] : 0);
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
@@ -110,11 +111,11 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
         const int n = (a.dir > 0) ? step : (NT - 1 - step);
         const double sdt = (a.dir > 0) ? a.dt[n] : -a.dt[n];
         double e[LMAX];
-        double theta = a.nrm[0];
+        double theta = gx.nrm[0];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             e[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0;
-            theta += fabs(e[l]) * a.nrm[1 + l];
+            theta += fabs(e[l]) * gx.nrm[1 + l];
         }
         theta *= fabs(sdt);
         int s, m;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
 #pragma unroll
                 for (int q = 0; q < KT; ++q) xp[q] = (j == m) ? &sx[cur][q][xoff] : &sy[w ^ 1][q][xoff];
                 double sr[KT][1], si[KT][1];
-                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(a.Hpack, tt, L, e, xp, sr, si);
+                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(gx.Hpack, tt, L, e, xp, sr, si);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     const double yr = fma(f, si[q][0], pr[q]);
@@ -171,6 +172,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
     const double my_thr = kr_load_my_thr(a);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x] : 0);
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
@@ -204,12 +206,12 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
 #pragma unroll
         for (int q = 0; q < KT; ++q) xp[q] = &sx[cur][q][xoff];
         double orr[KT][1 + LMAX], oi[KT][1 + LMAX];
-        kr_stream_rows<JS, JQ, RT, LMAX, KT, 1 + LMAX>(a.Hpack, tt, L, eg, xp, orr, oi);
+        kr_stream_rows<JS, JQ, RT, LMAX, KT, 1 + LMAX>(gx.Hpack, tt, L, eg, xp, orr, oi);
         double part[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             part[l] = 0.0;
-            if (l < L && ((a.present_mask >> l) & 1u)) {
+            if (l < L && ((gx.present >> l) & 1u)) {
 #pragma unroll
                 for (int q = 0; q < KT; ++q) part[l] += cr[q] * oi[q][1 + l] - ci[q] * orr[q][1 + l];
             }
@@ -225,7 +227,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
         if (!kr_exchange<LMAX, ROWS>(a, n, wg, writer, i, part, du, spart, stot)) return;
 
         double e[LMAX], de[LMAX];
-        double theta = a.nrm[0];
+        double theta = gx.nrm[0];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             e[l] = 0.0; de[l] = 0.0;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
                 de[l] = e[l] - eg[l];
                 const double ad = fabs(du[l]);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(al[l], __dmul_rn(ad, ad)), dt));
-                theta += fabs(e[l]) * a.nrm[1 + l];
+                theta += fabs(e[l]) * gx.nrm[1 + l];
                 if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = e[l];
             }
         }
@@ -261,7 +263,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
 #pragma unroll
                 for (int q = 0; q < KT; ++q) xp[q] = &sy[w ^ 1][q][xoff];
                 double sr[KT][1], si[KT][1];
-                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(a.Hpack, tt, L, e, xp, sr, si);
+                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(gx.Hpack, tt, L, e, xp, sr, si);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     yr[q] = fma(f, si[q][0], vr[q]);
@@ -286,7 +288,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
 #pragma unroll
                 for (int q = 0; q < KT; ++q) xp[q] = (j == m) ? &sx[cur][q][xoff] : &sy[w ^ 1][q][xoff];
                 double sr[KT][1], si[KT][1];
-                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(a.Hpack, tt, L, e, xp, sr, si);
+                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(gx.Hpack, tt, L, e, xp, sr, si);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     const double y_r = fma(f, si[q][0], pr[q]);

@@ -37,9 +37,15 @@ struct kr_handle {
     kr_launch_fn launch = nullptr;
     bool store_fw = true;
     double tol = 1e-16;
-    double nrm_fw[1 + KR_LMAX_CAP]{}, nrm_bw[1 + KR_LMAX_CAP]{};
     double thr[KR_MAX_ORDER]{};
-    unsigned present_mask = 0;
+    // per-trajectory generators: trajectories are grouped by generator, every workgroup tile is homogeneous
+    int G = 1;
+    std::vector<int> perm;        // user trajectory k -> internal slot in the [Kp][N] buffers
+    bool identity_perm = true;
+    size_t pack_stride = 0;
+    int *wg_gen_d = nullptr;
+    double *nrm_d = nullptr;
+    unsigned *present_d = nullptr;
     // device buffers
     double2 *Hpack_fw = nullptr, *Hpack_bw = nullptr;
     double *dt_d = nullptr, *eps_a = nullptr, *eps_b = nullptr, *S_d = nullptr, *lambda_d = nullptr, *gint_d = nullptr;
@@ -186,7 +192,7 @@ __global__ void kr_chi_kernel(int functional, const double2 *tgt, const double2 
 }
 
 // ---- plan -------------------------------------------------------------------------------------
-static int make_plan(kr_handle *h) {
+static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) {
     const kr_config &c = h->cfg;
     if (c.N > 256) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 256 is not supported by this build", c.N);
     if (c.L > KR_LMAX_CAP) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > %d controls not supported by this build", c.L, KR_LMAX_CAP);
@@ -221,16 +227,41 @@ static int make_plan(kr_handle *h) {
     if (maxwg < 1) maxwg = 1;
     int kt = env_int("KROTOV_HIP_KT", 0);
     if (kt != 0 && kt != 1 && kt != 2 && kt != 4) return fail(h, KR_ERR_INVALID, "KROTOV_HIP_KT must be 1, 2 or 4");
+    // trajectories per generator (tiles never mix generators)
+    std::vector<int> count(h->G, 0);
+    for (int k = 0; k < c.K; ++k) count[tg ? tg[k] : 0]++;
+    auto tiles_for = [&](int ktv) {
+        int t = 0;
+        for (int g = 0; g < h->G; ++g) t += (count[g] + h->SG * ktv - 1) / (h->SG * ktv);
+        return t;
+    };
     if (kt == 0) {
         kt = 1;
-        while (kt < 4 && (c.K + h->SG * kt - 1) / (h->SG * kt) > maxwg) kt <<= 1;
+        while (kt < 4 && tiles_for(kt) > maxwg) kt <<= 1;
     }
     h->KT = kt;
     h->KTILE = h->SG * kt;
-    h->P = (c.K + h->KTILE - 1) / h->KTILE;
+    h->P = tiles_for(kt);
     if (h->P > maxwg)
-        return fail(h, KR_ERR_UNSUPPORTED, "K = %d trajectories need %d co-resident workgroups (> %d CUs) at NP = %d", c.K, h->P, maxwg, NP);
+        return fail(h, KR_ERR_UNSUPPORTED, "K = %d trajectories (%d generators) need %d co-resident workgroups (> %d CUs) at NP = %d", c.K, h->G, h->P, maxwg, NP);
     h->Kp = h->P * h->KTILE;
+    // internal slots: generator groups one after the other, each padded to whole tiles
+    h->perm.assign(c.K, 0);
+    wg_gen.assign(h->P, 0);
+    std::vector<int> tile_base(h->G, 0), seen(h->G, 0);
+    int t = 0;
+    for (int g = 0; g < h->G; ++g) {
+        tile_base[g] = t;
+        const int nt = (count[g] + h->KTILE - 1) / h->KTILE;
+        for (int q = 0; q < nt; ++q) wg_gen[t + q] = g;
+        t += nt;
+    }
+    h->identity_perm = true;
+    for (int k = 0; k < c.K; ++k) {
+        const int g = tg ? tg[k] : 0;
+        h->perm[k] = tile_base[g] * h->KTILE + seen[g]++;
+        if (h->perm[k] != k) h->identity_perm = false;
+    }
     return KR_OK;
 }
 
@@ -240,7 +271,7 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
-                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d};
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -271,7 +302,11 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     if (cfg->L <= 0) return fail(nullptr, KR_ERR_INVALID, "no controls in trajectories: cannot optimize");  // workspace.jl:72
     if (cfg->N <= 0 || cfg->NT <= 0 || cfg->K <= 0) return fail(nullptr, KR_ERR_INVALID, "kr_create: N, NT, K must be positive (got %d, %d, %d)", cfg->N, cfg->NT, cfg->K);
     if (!cfg->tlist || !cfg->H0 || !cfg->Hc) return fail(nullptr, KR_ERR_INVALID, "kr_create: tlist, H0, Hc are required");
-    if (cfg->G != 1 || cfg->traj_generator) return fail(nullptr, KR_ERR_UNSUPPORTED, "kr_create: per-trajectory generators (G = %d) are not built yet; G must be 1", cfg->G);
+    if (cfg->G < 1 || cfg->G > cfg->K) return fail(nullptr, KR_ERR_INVALID, "kr_create: G = %d must be in 1..K", cfg->G);
+    if (cfg->G > 1 && !cfg->traj_generator) return fail(nullptr, KR_ERR_INVALID, "kr_create: G = %d > 1 needs traj_generator", cfg->G);
+    if (cfg->traj_generator)
+        for (int k = 0; k < cfg->K; ++k)
+            if (cfg->traj_generator[k] < 0 || cfg->traj_generator[k] >= cfg->G) return fail(nullptr, KR_ERR_INVALID, "kr_create: traj_generator[%d] = %d out of range", k, cfg->traj_generator[k]);
     if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world || cfg->world > 8) return fail(nullptr, KR_ERR_INVALID, "kr_create: bad rank/world %d/%d", cfg->rank, cfg->world);
     for (int n = 0; n < cfg->NT; ++n)
         if (!(cfg->tlist[n + 1] > cfg->tlist[n])) return fail(nullptr, KR_ERR_INVALID, "kr_create: tlist must be strictly increasing (index %d)", n);
@@ -311,31 +346,45 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     auto bail = [&](int code) { g_create_error = h->err; (void)hipSetDevice(dev); free_all(h); delete h; return code; };
 #define CHK(call) do { hipError_t e2_ = (call); if (e2_ != hipSuccess) { fail(h, KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2_)); return bail(KR_ERR_HIP); } } while (0)
     CHK(hipSetDevice(dev));
-    rc = make_plan(h);
+    h->G = cfg->G;
+    std::vector<int> wg_gen;
+    rc = make_plan(h, cfg->traj_generator, wg_gen);
     if (rc != KR_OK) return bail(rc);
     CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
 
     const int N = cfg->N, NT = cfg->NT, L = cfg->L, NP = h->NP;
     const size_t nn = (size_t)N * N;
-    // norms and packs
+    // norms, presence masks and packs, per generator
+    const int G = h->G;
     const zc *H0 = (const zc *)cfg->H0, *Hc = (const zc *)cfg->Hc;
-    h->present_mask = 0;
-    h->nrm_fw[0] = h->nrm_bw[0] = norm2_bound(N, H0);
-    for (int l = 0; l < L; ++l) {
-        const bool present = !cfg->hc_present || cfg->hc_present[l];
-        if (present) h->present_mask |= 1u << l;
-        h->nrm_fw[1 + l] = h->nrm_bw[1 + l] = norm2_bound(N, Hc + (size_t)l * nn);
-    }
-    const size_t pack_elems = (size_t)(1 + L) * h->JS * h->RT;
+    std::vector<double> nrm((size_t)G * (1 + KR_LMAX_CAP), 0.0);
+    std::vector<unsigned> present(G, 0u);
+    h->pack_stride = (size_t)(1 + L) * h->JS * h->RT;
+    const size_t pack_elems = h->pack_stride * G;
     std::vector<double2> pack(pack_elems);
     CHK(dalloc(&h->Hpack_fw, pack_elems));
     CHK(dalloc(&h->Hpack_bw, pack_elems));
+    for (int g = 0; g < G; ++g) {
+        nrm[(size_t)g * (1 + KR_LMAX_CAP)] = norm2_bound(N, H0 + (size_t)g * nn);
+        for (int l = 0; l < L; ++l) {
+            if (!cfg->hc_present || cfg->hc_present[(size_t)g * L + l]) present[g] |= 1u << l;
+            nrm[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l] = norm2_bound(N, Hc + ((size_t)g * L + l) * nn);
+        }
+    }
     for (int adj = 0; adj < 2; ++adj) {
-        for (int m = 0; m <= L; ++m)
-            pack_generator(N, NP, h->JQ, m == 0 ? H0 : Hc + (size_t)(m - 1) * nn, adj != 0, pack.data() + (size_t)m * h->JS * h->RT);
+        for (int g = 0; g < G; ++g)
+            for (int m = 0; m <= L; ++m)
+                pack_generator(N, NP, h->JQ, m == 0 ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn, adj != 0,
+                               pack.data() + (size_t)g * h->pack_stride + (size_t)m * h->JS * h->RT);
         CHK(hipMemcpy(adj ? h->Hpack_bw : h->Hpack_fw, pack.data(), pack_elems * sizeof(double2), hipMemcpyHostToDevice));
     }
+    CHK(dalloc(&h->nrm_d, nrm.size()));
+    CHK(hipMemcpy(h->nrm_d, nrm.data(), nrm.size() * sizeof(double), hipMemcpyHostToDevice));
+    CHK(dalloc(&h->present_d, (size_t)G));
+    CHK(hipMemcpy(h->present_d, present.data(), G * sizeof(unsigned), hipMemcpyHostToDevice));
+    CHK(dalloc(&h->wg_gen_d, (size_t)h->P));
+    CHK(hipMemcpy(h->wg_gen_d, wg_gen.data(), h->P * sizeof(int), hipMemcpyHostToDevice));
     std::vector<double> dt(NT);
     for (int n = 0; n < NT; ++n) dt[n] = cfg->tlist[n + 1] - cfg->tlist[n];
     CHK(dalloc(&h->dt_d, NT));
@@ -355,9 +404,9 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     // Known-pulse sweeps with precomputed propagators (kr_device_prop.h): N <= 64, and the U buffer
     // (NT * NP^2 * 16 B) within a budget; KROTOV_HIP_PRECOMP=0 keeps the Taylor sweeps.
     {
-        const size_t ubytes = (size_t)NT * NP * NP * sizeof(double2);
+        const size_t ubytes = (size_t)G * NT * NP * NP * sizeof(double2);
         h->precomp = (NP <= 64) && env_int("KROTOV_HIP_PRECOMP", 1) != 0 && ubytes <= ((size_t)8 << 30);
-        if (h->precomp) CHK(dalloc(&h->U_d, (size_t)NT * NP * NP));
+        if (h->precomp) CHK(dalloc(&h->U_d, (size_t)G * NT * NP * NP));
     }
     CHK(dalloc(&h->tau_d, h->Kp));
     CHK(dalloc(&h->tausum_d, 1));
@@ -452,9 +501,17 @@ extern "C" int kr_debug_stamps(kr_handle *h, unsigned long long *out) {
     return KR_OK;
 }
 
-// copy [K][N] host states into the zero-padded [Kp][N] device buffer
+// copy [K][N] host states into the zero-padded [Kp][N] device buffer (grouped by generator)
 static int upload_states(kr_handle *h, double2 *dst, const double *src) {
-    HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)h->cfg.K * h->cfg.N * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+    const size_t N = h->cfg.N, K = h->cfg.K;
+    if (h->identity_perm) {
+        HIPCHK(h, hipMemcpyAsync(dst, src, K * N * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+        return KR_OK;
+    }
+    h->stage.assign((size_t)h->Kp * N * 2, 0.0);
+    for (size_t k = 0; k < K; ++k) memcpy(&h->stage[(size_t)h->perm[k] * N * 2], src + k * N * 2, N * sizeof(double2));
+    HIPCHK(h, hipMemcpyAsync(dst, h->stage.data(), (size_t)h->Kp * N * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // stage is reused
     return KR_OK;
 }
 
@@ -487,7 +544,10 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.P = h->P; a.rank = h->cfg.rank; a.world = h->cfg.world;
     a.tol = h->tol;
     memcpy(a.thr, h->thr, sizeof a.thr);
-    a.present_mask = h->present_mask;
+    a.pack_stride = h->pack_stride;
+    a.wg_gen = (h->G > 1) ? h->wg_gen_d : nullptr;
+    a.nrm_dev = h->nrm_d;
+    a.present_dev = h->present_d;
     a.status = h->status_d;
     a.debug = h->debug_on ? h->debug_d : nullptr;
     a.mail = h->mail_d;
@@ -499,7 +559,6 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     KrSweepArgs a;
     base_args(h, a);
     a.Hpack = backward ? h->Hpack_bw : h->Hpack_fw;
-    memcpy(a.nrm, backward ? h->nrm_bw : h->nrm_fw, sizeof a.nrm);
     a.eps = eps_dev;
     a.init = init; a.store = store; a.fin = fin;
     a.dir = backward ? -1 : +1;
@@ -508,7 +567,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     if (rc) return rc;
     if (h->precomp) {
         // all N_T step propagators in parallel, then one matvec round per step
-        HIPCHK(h, h->launch(h->LMAXv, h->KT, 2, h->cfg.NT, h->stream, &a));
+        HIPCHK(h, h->launch(h->LMAXv, h->KT, 2, h->cfg.NT * h->G, h->stream, &a));
         HIPCHK(h, h->launch(h->LMAXv, h->KT, 3, h->P, h->stream, &a));
     } else {
         HIPCHK(h, h->launch(h->LMAXv, h->KT, 0, h->P, h->stream, &a));
@@ -522,7 +581,6 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     KrSweepArgs a;
     base_args(h, a);
     a.Hpack = h->Hpack_fw;
-    memcpy(a.nrm, h->nrm_fw, sizeof a.nrm);
     a.eps = eps_guess_dev;
     a.init = h->psi0_d; a.store = h->store_fw ? h->Phi_d : nullptr; a.fin = h->psiT_d;
     a.X = h->X_d; a.alpha = h->S_d; a.eps_new = eps_new_dev; a.g_a_int = h->gint_d;
@@ -548,7 +606,15 @@ static int check_status(kr_handle *h) {
 
 static int download_states(kr_handle *h, double *dst, const double2 *src) {
     if (!dst) return KR_OK;
-    HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)h->cfg.K * h->cfg.N * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    const size_t N = h->cfg.N, K = h->cfg.K;
+    if (h->identity_perm) {
+        HIPCHK(h, hipMemcpyAsync(dst, src, K * N * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+        return KR_OK;
+    }
+    h->stage.resize((size_t)h->Kp * N * 2);
+    HIPCHK(h, hipMemcpyAsync(h->stage.data(), src, (size_t)h->Kp * N * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t k = 0; k < K; ++k) memcpy(dst + k * N * 2, &h->stage[(size_t)h->perm[k] * N * 2], N * sizeof(double2));
     return KR_OK;
 }
 
@@ -666,7 +732,7 @@ extern "C" int kr_forward_dev(kr_handle *h, const void *eps_dev) {
 }
 
 static int launch_tau(kr_handle *h) {
-    const int K = h->cfg.K, N = h->cfg.N;
+    const int K = h->Kp, N = h->cfg.N;  // padded slots have zero targets -> tau = 0
     hipLaunchKernelGGL(kr_tau_kernel, dim3((K + 3) / 4), dim3(256), 0, h->stream, h->tgt_d, h->psiT_d, h->tau_d, N, K);
     HIPCHK(h, hipGetLastError());
     return KR_OK;
@@ -682,7 +748,7 @@ extern "C" int kr_iteration_functional_dev(kr_handle *h, int functional, const v
     if (functional == KR_J_T_SM && h->cfg.world > 1)
         return fail(h, KR_ERR_UNSUPPORTED, "J_T_sm couples trajectories across ranks; use the host chi path for world > 1");
     HIPCHK(h, hipSetDevice(h->device));
-    const int K = h->cfg.K, N = h->cfg.N;
+    const int K = h->Kp, N = h->cfg.N;
     int rc = launch_tau(h);
     if (rc) return rc;
     if (functional == KR_J_T_SM) {
@@ -726,8 +792,10 @@ extern "C" int kr_taus(kr_handle *h, double *tau_out) {
     HIPCHK(h, hipSetDevice(h->device));
     int rc = launch_tau(h);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(tau_out, h->tau_d, (size_t)h->cfg.K * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    h->stage.resize((size_t)h->Kp * 2);
+    HIPCHK(h, hipMemcpyAsync(h->stage.data(), h->tau_d, (size_t)h->Kp * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < h->cfg.K; ++k) { tau_out[2 * k] = h->stage[2 * (size_t)h->perm[k]]; tau_out[2 * k + 1] = h->stage[2 * (size_t)h->perm[k] + 1]; }
     return KR_OK;
 }
 
@@ -749,7 +817,7 @@ extern "C" int kr_read_storage(kr_handle *h, int which, int k, int n, double *ou
     else if (which == KR_STORAGE_FW) { if (!h->store_fw) return fail(h, KR_ERR_STATE, "forward storage disabled (KR_NO_STORE_FW)"); if (!h->have_final) return fail(h, KR_ERR_STATE, "forward storage is empty"); base = h->Phi_d; }
     else return fail(h, KR_ERR_INVALID, "kr_read_storage: which = %d", which);
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t off = ((size_t)n * h->Kp + k) * h->cfg.N;
+    const size_t off = ((size_t)n * h->Kp + h->perm[k]) * h->cfg.N;
     HIPCHK(h, hipMemcpyAsync(out, base + off, (size_t)h->cfg.N * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return KR_OK;

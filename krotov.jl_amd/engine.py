@@ -14,27 +14,44 @@ from . import _capi as capi
 
 
 class HipEngine:
-    def __init__(self, H0, Hc, tlist, K, *, hc_present=None, store_fw=True, prop_tol=0.0, device=-1,
-                 rank=0, world=1, K_global=0):
+    def __init__(self, H0, Hc, tlist, K, *, hc_present=None, traj_generator=None, store_fw=True, prop_tol=0.0,
+                 device=-1, rank=0, world=1, K_global=0):
+        """H0 (N,N) and Hc (L,N,N) for a generator shared by all trajectories, or H0 (G,N,N), Hc (G,L,N,N)
+        with traj_generator[k] in 0..G-1 for per-trajectory generators (control_derivs[k][l],
+        /root/reference/src/workspace.jl:74)."""
         lib = capi.load()
         self._lib = lib
         self._h = C.c_void_p()
         H0 = np.asarray(H0, np.complex128)
         Hc = np.asarray(Hc, np.complex128)
-        if Hc.ndim == 2:
-            Hc = Hc[None]
+        if H0.ndim == 2:
+            G = 1
+            if Hc.ndim == 2:
+                Hc = Hc[None]
+        else:
+            G = H0.shape[0]
+            if Hc.ndim != 4 or Hc.shape[0] != G:
+                raise ValueError("per-trajectory generators need H0 (G,N,N) and Hc (G,L,N,N)")
         tl = np.ascontiguousarray(tlist, np.float64)
-        self.N = int(H0.shape[0])
-        self.L = int(Hc.shape[0]) if Hc.size else 0
+        self.N = int(H0.shape[-1])
+        self.L = int(Hc.shape[-3]) if Hc.size else 0
         self.NT = len(tl) - 1
         self.K = int(K)
+        self.G = G
         self.rank, self.world = rank, world
         H0c, Hcc = capi.colmajor(H0), capi.colmajor(Hc)
         pres = None if hc_present is None else np.ascontiguousarray(hc_present, np.uint8)
+        tg = None
+        if G > 1:
+            if traj_generator is None:
+                raise ValueError("traj_generator is required when G > 1")
+            tg = np.ascontiguousarray(traj_generator, np.int32)
+            if tg.shape != (self.K,):
+                raise ValueError("traj_generator must have length K")
         cfg = capi.KrConfig()
         cfg.abi_version = capi.KR_ABI_VERSION
-        cfg.N, cfg.NT, cfg.K, cfg.L, cfg.G = self.N, self.NT, self.K, self.L, 1
-        cfg.traj_generator = None
+        cfg.N, cfg.NT, cfg.K, cfg.L, cfg.G = self.N, self.NT, self.K, self.L, G
+        cfg.traj_generator = capi.ptr(tg)
         cfg.tlist, cfg.H0, cfg.Hc = capi.ptr(tl), capi.ptr(H0c), capi.ptr(Hcc)
         cfg.hc_present = capi.ptr(pres)
         cfg.flags = capi.KR_STORE_FW if store_fw else capi.KR_NO_STORE_FW

@@ -263,27 +263,42 @@ class KrotovWrk:
         self.chi_takes_tau = _takes_tau(kwargs["chi"])
 
         # ---- the device engine replaces fw/bw propagators and the three storages (workspace.jl:128-161)
-        gen0 = self.trajectories[0].generator
-        for traj in self.trajectories[1:]:
+        # distinct generators (by identity, or by value) -> G packs + the k -> g map
+        gens, traj_gen = [], []
+        for traj in self.trajectories:
             g = traj.generator
-            same = (g is gen0) or (np.array_equal(g.H0, gen0.H0) and len(g.ops) == len(gen0.ops)
-                                   and all(np.array_equal(a, b) for a, b in zip(g.ops, gen0.ops))
-                                   and all(a is b for a, b in zip(g.controls, gen0.controls)))
-            if not same:
-                raise NotImplementedError("per-trajectory generators (G > 1) are not built yet (SURVEY 8f rank 4)")
-        N = gen0.H0.shape[0]
-        Hc = np.zeros((len(self.controls), N, N), np.complex128)
-        present = np.zeros(len(self.controls), np.uint8)
-        for l, c in enumerate(self.controls):  # control_derivs[k][l] (workspace.jl:74); `nothing` -> absent
-            for op, gc in zip(gen0.ops, gen0.controls):
-                if gc is c:
-                    Hc[l] += op
-                    present[l] = 1
-        self.control_derivs = [[Hc[l] if present[l] else None for l in range(len(self.controls))]
-                               for _ in self.trajectories]
+            idx = None
+            for q, other in enumerate(gens):
+                if g is other or (np.array_equal(g.H0, other.H0) and len(g.ops) == len(other.ops)
+                                  and all(np.array_equal(a, b) for a, b in zip(g.ops, other.ops))
+                                  and all(a is b for a, b in zip(g.controls, other.controls))):
+                    idx = q
+                    break
+            if idx is None:
+                gens.append(g)
+                idx = len(gens) - 1
+            traj_gen.append(idx)
+        N = gens[0].H0.shape[0]
+        G, L = len(gens), len(self.controls)
+        H0 = np.zeros((G, N, N), np.complex128)
+        Hc = np.zeros((G, L, N, N), np.complex128)
+        present = np.zeros((G, L), np.uint8)
+        for gi, g in enumerate(gens):
+            H0[gi] = g.H0
+            for l, c in enumerate(self.controls):  # control_derivs[k][l] (workspace.jl:74); `nothing` -> absent
+                for op, gc in zip(g.ops, g.controls):
+                    if gc is c:
+                        Hc[gi, l] += op
+                        present[gi, l] = 1
+        self.control_derivs = [[Hc[traj_gen[k], l] if present[traj_gen[k], l] else None for l in range(L)]
+                               for k in range(len(self.trajectories))]
         factory = kwargs.get("engine_factory", _default_engine_factory)
         ekw = {"prop_tol": float(kwargs["prop_tol"])} if "prop_tol" in kwargs else {}
-        self.engine = factory(gen0.H0, Hc, tlist, len(self.trajectories), hc_present=present, **ekw)
+        if G == 1:
+            self.engine = factory(H0[0], Hc[0], tlist, len(self.trajectories), hc_present=present[0], **ekw)
+        else:
+            self.engine = factory(H0, Hc, tlist, len(self.trajectories), hc_present=present,
+                                  traj_generator=np.array(traj_gen, np.int32), **ekw)
         self.engine.set_initial_states(np.array([t.initial_state for t in self.trajectories]))
         self.final_states = None
 

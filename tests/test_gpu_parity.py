@@ -245,3 +245,44 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(kr.KrotovHipError) as ei:
         kr.HipEngine(np.eye(300), np.eye(300)[None], np.linspace(0, 1, 3), 1)
     assert ei.value.code == kr._capi.KR_ERR_UNSUPPORTED
+
+
+def test_per_trajectory_generators(oracle_c):
+    """G > 1: an ensemble of different H_k (control_derivs[k][l], workspace.jl:74; optimize.jl:343).  The oracle
+    is run per generator group and the update integrands are summed over ALL trajectories by hand."""
+    import krotov_oracle as o
+    rng = np.random.default_rng(77)
+    N, NT, L = 12, 25, 2
+    G, K = 3, 8
+    tg = np.array([0, 2, 1, 0, 2, 2, 1, 0], np.int32)
+    base = wl.dense_problem(N, NT, K, L, 99, 0.1, 1.5)
+    H0 = np.array([base["H0"] * (1.0 + 0.1 * g) + 0.05 * wl.random_hermitian(rng, N) for g in range(G)])
+    Hc = np.array([[base["Hc"][l] * (1.0 - 0.07 * g) for l in range(L)] for g in range(G)])
+    present = np.ones((G, L), np.uint8)
+    present[1, 1] = 0   # generator 1 does not depend on control 1
+    tl, eps, S, lam, psi0, tgt = base["tlist"], base["eps"], base["S"], base["lam"], base["psi0"], base["tgt"]
+    with kr.HipEngine(H0, Hc, tl, K, traj_generator=tg, hc_present=present) as eng:
+        eng.set_initial_states(psi0)
+        psiT = eng.forward(eps)
+        # oracle forward per trajectory with its own generator
+        psiT_o = np.array([o.forward(H0[tg[k]], Hc[tg[k]], tl, eps, psi0[k:k + 1])[0][0] for k in range(K)])
+        assert np.max(np.abs(psiT - psiT_o)) < TOL_STATE
+        _, _, chiT = wl.chi_and_JT("ss", psiT_o, tgt)
+        eps_new, ga, psiT1 = eng.iteration(eps, chiT, S, lam)
+        X0 = eng.read_storage("bw", 5, 0)
+    # oracle update sweep with per-trajectory generators (serial restatement of optimize.jl:328-370)
+    X = [o.backward(H0[tg[k]], Hc[tg[k]], tl, eps, chiT[k:k + 1])[:, 0] for k in range(K)]
+    assert np.max(np.abs(X0 - X[5][0])) < TOL_STATE
+    psi = psi0.copy()
+    eps_o = eps.copy()
+    for n in range(NT):
+        du = np.zeros(L)
+        for l in range(L):
+            for k in range(K):
+                if present[tg[k], l]:
+                    du[l] += np.vdot(X[k][n], Hc[tg[k], l] @ psi[k]).imag
+        eps_o[:, n] = eps[:, n] + S[:, n] / lam * du
+        for k in range(K):
+            psi[k] = o.step_propagator(H0[tg[k]], Hc[tg[k]], eps_o[:, n], tl[n + 1] - tl[n]) @ psi[k]
+    assert _rel(eps_new, eps_o) < TOL_PULSE
+    assert np.max(np.abs(psiT1 - psi)) < 1e-10

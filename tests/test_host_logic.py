@@ -148,3 +148,22 @@ def test_exception_is_captured():
     assert res.message.startswith("Exception:") and not res.converged
     with pytest.raises(KeyboardInterrupt):
         kr.optimize(tls_problem(iter_stop=3, J_T=kr.J_T_sm), callback=bad, print_iters=False, rethrow_exceptions=True)
+
+
+def test_ensemble_of_generators_through_driver():
+    """Robustness ensemble: the same control drives three TLS with different detunings (distinct generators per
+    trajectory, control_derivs[k][l]: workspace.jl:74).  The driver must hand G = 3 generators to the engine
+    and J_T_ss must decrease."""
+    eps = lambda t: 0.2 * kr.flattop(t, T=5, t_rise=0.3)
+    H1 = np.array([[0, 1], [1, 0]], complex)
+    tlist = np.linspace(0, 5, 101)
+    trajs = []
+    for om in (0.9, 1.0, 1.1):
+        H = kr.hamiltonian(-0.5 * om * np.array([[1, 0], [0, -1]], complex), (H1, eps))
+        trajs.append(kr.Trajectory(np.array([1, 0], complex), H, target_state=np.array([0, 1], complex)))
+    trajs.append(kr.Trajectory(np.array([0, 1], complex), trajs[1].generator, target_state=np.array([1, 0], complex)))
+    problem = kr.ControlProblem(trajs, tlist, iter_stop=3, J_T=kr.J_T_ss, engine_factory=factory, keep_engine=True)
+    out = io.StringIO()
+    res = kr.optimize(problem, store_iter_info=["J_T"], print_iters_out=out)
+    J = [r[0] for r in res.records]
+    assert J[3] < J[2] < J[1] < J[0]
