@@ -606,13 +606,6 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         if (!kr_exchange<LMAX, 64>(a, n, wg, writer, rowid, part, du, spart, stot)) return;
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 
-        // memory wave: start fetching chi(t_{n+1}); it lands while the Taylor rounds run
-        if (memwave && n + 1 < NT) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (m_tq[c] >= 0) cpf[c] = a.X[(size_t)(n + 1) * slab + tile_base + lane + 64 * c];
-        }
-
         // ---- pulse update (optimize.jl:351-358), identical on every workgroup ---------------
         double e[LMAX], de[LMAX];
         double theta = gx.nrm[0];
@@ -660,6 +653,14 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 if (m > 1 && writer) sy[0][q * SG + team][pi_] = make_double2(vr[q], vi[q]);
             }
             if (m > 1) __syncthreads();
+            // memory wave: start fetching chi(t_{n+1}); it lands while the Taylor rounds run
+            if (memwave && n + 1 < NT) {
+                // unconditional loads from a clamped address: a per-lane conditional assignment would make the compiler
+                // wait for the data right here (select against the old register value) -- a full HBM latency per step
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                        cpf[c] = a.X[(size_t)(n + 1) * slab + tile_base + min(lane + 64 * c, tile_elems - 1)];
+            }
             if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB1 += t - t_prev; }
             int w = 1;
             double yr[KT], yi[KT];
