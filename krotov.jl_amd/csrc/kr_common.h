@@ -43,6 +43,7 @@ struct KrSweepArgs {
     int rank, world;
     unsigned epoch_base;     // tags = epoch_base + n + 1
     int n_begin, n_end;      // step range of this launch (update sweep may be split)
+    int use_mfma;            // propagator build on the matrix cores where available (NP = 64)
 };
 
 // Taylor plan: sub-steps s and order m so that the truncation bound of exp(A), ||A|| <= theta,

@@ -23,6 +23,7 @@
 //                     psi_k <- U_n(eps_new) psi_k (:360-368).
 #pragma once
 #include "kr_common.h"
+#include <cstdlib>
 
 template <int NP, int LMAX, int KT>
 struct KrGeom {
@@ -752,6 +753,22 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 
 // ---- launcher table for one NP ---------------------------------------------------------------
 #include "kr_device_prop.h"
+// propagator build: matrix cores for NP = 64 (KROTOV_HIP_EXPM_MFMA=0 at kr_create selects the VALU kernel)
+template <int NP, int LM, int CB>
+static void kr_launch_expm(int grid, hipStream_t s, const KrSweepArgs *a) {
+    if constexpr (NP == 64) {
+        if (a->use_mfma) {
+            constexpr size_t lds = (size_t)4 * 64 * KR_YS * sizeof(double);
+            static const bool ok = hipFuncSetAttribute((const void *)kr_expm_mfma64<LM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL((kr_expm_mfma64<LM>), dim3(grid), dim3(256), lds, s, *a);
+                return;
+            }
+        }
+    }
+    hipLaunchKernelGGL((kr_expm_batch<NP, LM, CB>), dim3(grid), dim3(KrGeom<NP, LM, 1>::THREADS), 0, s, *a);
+}
+
 template <int NP>
 static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
     constexpr int CB = (NP >= 16) ? 4 : 1;
@@ -759,7 +776,7 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
     if (lmax == LM && kt == KTv) {                                                                \
         if (kind == 0) hipLaunchKernelGGL((kr_sweep_known<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
         else if (kind == 1) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else if (kind == 2) hipLaunchKernelGGL((kr_expm_batch<NP, LM, CB>), dim3(grid), dim3(KrGeom<NP, LM, 1>::THREADS), 0, s, *a); \
+        else if (kind == 2) { kr_launch_expm<NP, LM, CB>(grid, s, a); }                              \
         else hipLaunchKernelGGL((kr_sweep_apply<NP, KTv>), dim3(grid), dim3(256), 0, s, *a);      \
         return hipGetLastError();                                                                 \
     }

@@ -195,3 +195,126 @@ __global__ __launch_bounds__(256, 1) void kr_sweep_apply(const KrSweepArgs a) {
         }
     }
 }
+
+// ---- batched propagator construction on the matrix cores, NP = 64 ------------------------------------
+// U_n = exp(A), A = -i sdt H(eps_n): scaling and squaring around the same Taylor/Horner polynomial,
+//   Y <- I + (A / (2^q j)) Y  (j = m..1),  then q squarings,  2^q >= ||A|| (q = 0 for the usual ||A|| <= 1),
+// with every 64x64x64 complex product done as 4 real products on v_mfma_f64_16x16x4_f64 (64 cycles per
+// instruction per SIMD, measured: tools/ubench/mfma64.hip = the fp64 peak, reached by one wave per SIMD).
+// Wave w owns output rows 16w..16w+15; its A fragments (16 k-steps x {re, im, -im}) stay in registers for all
+// rounds; Y lives in LDS as separate re / im planes (ping-pong), read as MFMA B fragments.
+// Fragment maps (gfx950, checked in the micro-benchmark): A: lane l holds A[l & 15][l >> 4]; B: lane l holds
+// B[l >> 4][l & 15]; D register r of lane l is D[(l >> 4) + 4 r][l & 15].
+typedef double kr_d4 __attribute__((ext_vector_type(4)));
+#define KR_YS 66  // row stride (doubles) of the LDS planes
+
+template <int LMAX>
+__global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
+    constexpr int NP = 64;
+    // producer-side pack geometry (how Hpack was written for NP = 64, see KrGeom)
+    using G = KrGeom<NP, LMAX, 1>;
+    constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT;
+    constexpr int JS_A = NP / 4, RT_A = 4 * NP;
+    extern __shared__ __attribute__((aligned(16))) double kr_lds[];
+    // planes: [buffer b][re | im][64][KR_YS]
+#define KR_YR(b) (kr_lds + (size_t)(b) * 2 * NP * KR_YS)
+#define KR_YI(b) (kr_lds + (size_t)(b) * 2 * NP * KR_YS + NP * KR_YS)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
+    const double my_thr = kr_load_my_thr(a);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, blockIdx.x / a.NT);
+    const int NT = a.NT, L = a.L;
+    const int n = blockIdx.x % NT;
+    const double sdt = (a.dir > 0) ? a.dt[n] : -a.dt[n];
+
+    double e[LMAX];
+    double theta = gx.nrm[0];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        e[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0;
+        theta += fabs(e[l]) * gx.nrm[1 + l];
+    }
+    theta *= fabs(sdt);
+    int q = 0;
+    while (theta > KR_THETA_MAX && q < 30) { theta *= 0.5; ++q; }
+    int s_unused, m;
+    kr_plan_fast(a, my_thr, theta, s_unused, m);   // theta <= 1 here: table path
+    const double fs = ldexp(sdt, -q);
+
+    // A fragments: A = -i fs H  ->  Ar = fs Hi,  Ai = -fs Hr  (row 16w + li, column 4t + lk)
+    double Ar[16], Ai[16], nAi[16];
+    const int row = 16 * w + li;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int col = 4 * t + lk;
+        const size_t off = (size_t)(col % JS) * RT + (size_t)row * JQ + (col / JS);
+        const double2 h0 = gx.Hpack[off];
+        double hr = h0.x, hi = h0.y;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < L) {
+                const double2 hl = gx.Hpack[(size_t)(1 + l) * JS * RT + off];
+                hr = fma(e[l], hl.x, hr);
+                hi = fma(e[l], hl.y, hi);
+            }
+        }
+        Ar[t] = fs * hi;
+        Ai[t] = -fs * hr;
+        nAi[t] = fs * hr;
+    }
+    // Y = I
+    for (int idx = tid; idx < NP * NP; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        KR_YR(0)[r * KR_YS + c] = (r == c) ? 1.0 : 0.0;
+        KR_YI(0)[r * KR_YS + c] = 0.0;
+    }
+    __syncthreads();
+
+    int cur = 0;
+    const int rounds = m + q;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const bool horner = (rd < m);
+        const int j = m - rd;  // Horner index m..1
+        const double f = horner ? kr_rinv_lane(my_rinv, j) : 1.0;
+        if (!horner) {  // squaring: the A fragments become this wave's row tile of Y
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const double yr = KR_YR(cur)[row * KR_YS + 4 * t + lk], yi = KR_YI(cur)[row * KR_YS + 4 * t + lk];
+                Ar[t] = yr; Ai[t] = yi; nAi[t] = -yi;
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            kr_d4 cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const double br = KR_YR(cur)[(4 * t + lk) * KR_YS + 16 * ct + li];
+                const double bi = KR_YI(cur)[(4 * t + lk) * KR_YS + 16 * ct + li];
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[t], br, cr, 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(nAi[t], bi, cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[t], bi, ci, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[t], br, ci, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = 16 * w + lk + 4 * r, ocol = 16 * ct + li;
+                double vr = cr[r] * f, vi = ci[r] * f;
+                if (horner && orow == ocol) vr += 1.0;
+                KR_YR(cur ^ 1)[orow * KR_YS + ocol] = vr;
+                KR_YI(cur ^ 1)[orow * KR_YS + ocol] = vi;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // U_n -> thread-major pack of the apply kernel: Upack[jj * 256 + i*4 + jq] = U[i][jq*16 + jj]
+    double2 *Un = a.U + ((size_t)gx.gen * NT + n) * NP * NP;
+    const int i = tid >> 2, jq = tid & 3;
+#pragma unroll
+    for (int jj = 0; jj < JS_A; ++jj) {
+        const int c = jq * JS_A + jj;
+        Un[(size_t)jj * RT_A + tid] = make_double2(KR_YR(cur)[i * KR_YS + c], KR_YI(cur)[i * KR_YS + c]);
+    }
+}

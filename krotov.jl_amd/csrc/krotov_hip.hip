@@ -53,6 +53,7 @@ struct kr_handle {
     double2 *tau_d = nullptr, *tausum_d = nullptr;
     double2 *U_d = nullptr;   // precomputed step propagators of the known-pulse sweeps (N <= 64), or nullptr
     bool precomp = false;
+    bool use_mfma = true;
     unsigned long long *mail_d = nullptr, *xmail_d = nullptr;
     unsigned long long *peer_xmail[8]{};
     bool peers_connected = false;
@@ -406,6 +407,7 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     {
         const size_t ubytes = (size_t)G * NT * NP * NP * sizeof(double2);
         h->precomp = (NP <= 64) && env_int("KROTOV_HIP_PRECOMP", 1) != 0 && ubytes <= ((size_t)8 << 30);
+        h->use_mfma = env_int("KROTOV_HIP_EXPM_MFMA", 1) != 0;
         if (h->precomp) CHK(dalloc(&h->U_d, (size_t)G * NT * NP * NP));
     }
     CHK(dalloc(&h->tau_d, h->Kp));
@@ -544,6 +546,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.P = h->P; a.rank = h->cfg.rank; a.world = h->cfg.world;
     a.tol = h->tol;
     memcpy(a.thr, h->thr, sizeof a.thr);
+    a.use_mfma = h->use_mfma ? 1 : 0;
     a.pack_stride = h->pack_stride;
     a.wg_gen = (h->G > 1) ? h->wg_gen_d : nullptr;
     a.nrm_dev = h->nrm_d;

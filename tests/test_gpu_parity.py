@@ -350,3 +350,13 @@ def test_ensemble_through_driver_on_gpu():
     res = kr.optimize(problem, store_iter_info=["J_T"], print_iters_out=io.StringIO())
     J = [r[0] for r in res.records]
     assert all(b < a for a, b in zip(J, J[1:])) and res.converged
+
+
+def test_n64_large_norm_scaling_and_squaring(oracle_c, monkeypatch):
+    """N = 64 with ||H dt|| ~ 6: the matrix-core propagator build (kr_expm_mfma64) has to scale and square; the
+    update sweep has to sub-step.  Also run with the VALU build kernel."""
+    p = wl.dense_problem(64, 6, 5, 2, 101, 0.1, 50.0)
+    p["H0"] = p["H0"] * 60.0
+    for mfma in ("1", "0"):
+        monkeypatch.setenv("KROTOV_HIP_EXPM_MFMA", mfma)
+        _run_case(oracle_c, p, check_storage=True)
