@@ -571,7 +571,18 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     if (h->precomp) {
         // all N_T step propagators in parallel, then one matvec round per step
         HIPCHK(h, h->launch(h->LMAXv, h->KT, 2, h->cfg.NT * h->G, h->stream, &a));
-        HIPCHK(h, h->launch(h->LMAXv, h->KT, 3, h->P, h->stream, &a));
+        // The apply sweep is bound by streaming U_n (NP^2 * 16 B per workgroup per step) from L2: with a shared
+        // generator, wider tiles (more trajectories per workgroup, fewer workgroups) cut that traffic.
+        int kt_apply = h->KT;
+        if (h->G == 1) {
+            const int want = env_int("KROTOV_HIP_APPLY_KT", 0);
+            for (int cand : {4, 2}) {
+                if (cand <= kt_apply) break;
+                const bool pick = (cand == want);  // measured at C3: KT 1 -> 1.24 ms, 2 -> 1.44 ms, 4 -> 2.03 ms per sweep: default = the handle's KT
+                if (pick && h->Kp % (h->SG * cand) == 0) { kt_apply = cand; break; }
+            }
+        }
+        HIPCHK(h, h->launch(h->LMAXv, kt_apply, 3, h->Kp / (h->SG * kt_apply), h->stream, &a));
     } else {
         HIPCHK(h, h->launch(h->LMAXv, h->KT, 0, h->P, h->stream, &a));
     }
