@@ -90,6 +90,9 @@ def main():
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
     import torch
+    if rank == 0 and not os.path.exists(os.path.join(ROOT, "krotov.jl_amd", "lib", "libkrotov_hip.so")):
+        import __graft_entry__ as ge   # clean checkout: build the HIP library first (hipcc, gfx950)
+        ge.build()
     import krotov_jl_amd as kr
     from krotov_jl_amd import workloads as wl
     from krotov_jl_amd import distributed as krd

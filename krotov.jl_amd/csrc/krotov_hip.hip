@@ -428,7 +428,14 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     if (cfg->world > 1) {
         // inter-GPU mailbox: written by peers over xGMI, polled by this GPU's kernels -> uncached/fine-grained
         const size_t xwords = (size_t)2 * 8 * 2 * KR_LMAX_CAP;
-        CHK(hipExtMallocWithFlags((void **)&h->xmail_d, xwords * sizeof(unsigned long long), hipDeviceMallocUncached));
+        // preference: uncached, then fine-grained, then plain device memory (peers always use system-scope atomics)
+        if (hipExtMallocWithFlags((void **)&h->xmail_d, xwords * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipExtMallocWithFlags((void **)&h->xmail_d, xwords * sizeof(unsigned long long), hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                CHK(hipMalloc((void **)&h->xmail_d, xwords * sizeof(unsigned long long)));
+            }
+        }
         CHK(hipMemset(h->xmail_d, 0, xwords * sizeof(unsigned long long)));
         h->peer_xmail[cfg->rank] = h->xmail_d;
     }
