@@ -33,6 +33,8 @@ struct KrSweepArgs {
     unsigned long long *xmail; // [2][world][2*LMAX] inter-GPU granules (local memory, peers write)
     unsigned long long *peer_xmail[8]; // every rank's xmail (peer_xmail[rank] == xmail)
     double2 *U;              // [NT][NP*NP] precomputed step propagators, thread-major (kr_device_prop.h), or nullptr
+    unsigned long long *gmail; // row-split kernels: per-trajectory vector mailbox [tiles][2][NP][4] granules
+    unsigned epoch_base2;    // tag base of the vector mailbox for this launch
     unsigned *status;        // [KR_STATUS_WORDS]
     unsigned long long *debug; // nullptr, or [8]: workgroup 0's cycle counts per phase (diagnostics only)
     double tol;
@@ -119,3 +121,6 @@ hipError_t kr_launch_np32(int lmax, int kt, int kind, int grid, hipStream_t s, c
 hipError_t kr_launch_np64(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np128(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np256(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+// row-split kernels (kr_device_rowsplit.h): second argument = rows per workgroup
+hipError_t kr_launch_rs128(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+hipError_t kr_launch_rs256(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);

@@ -320,7 +320,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             double v = 0.0;
             if (l < L) {
 #pragma unroll
-                for (int r = 0; r < ROWS; r += 64) v += spart[l * ROWS + r + lane];
+                for (int r = 0; r < ROWS; r += 64) if (r + lane < ROWS) v += spart[l * ROWS + r + lane];
                 v = kr_wave_sum(v);
             }
             tot[l] = v;

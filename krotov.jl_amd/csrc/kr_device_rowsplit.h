@@ -1,0 +1,407 @@
+// Row-split sweep kernels for 64 < N <= 256 (NP in {128, 256}): R workgroups share ONE trajectory.
+//
+// With K < #CUs and N large, one workgroup per trajectory leaves most of the chip idle and has to stream the
+// whole generator (N = 256: 1 MB per matrix) from L2 for every matvec round (kr_device_stream.h: 16 us per
+// round).  Here workgroup (tile, rb) owns rows [rb*NR, (rb+1)*NR) of the generator: its block of H(eps) stays in
+// registers for all rounds of a step (NR = 64, NP = 256: 128 VGPRs per thread), the blocks of H0, H_l are streamed
+// once (known-pulse sweeps) or twice (update sweep) per STEP, and after every matvec round the R workgroups of a
+// trajectory all-gather the N new vector elements through a tagged mailbox (4 eight-byte granules
+// {tag32 | 32 bits} per complex element, agent-scope atomics, double-buffered by round parity, bounded spins).
+// The per-step global sum of the update integrands runs over all P = K*R workgroups with kr_exchange, each
+// workgroup contributing the rows it owns.
+//
+// Thread map: T = 512 threads (1024 for NR = 64); thread (il, jq) = (tid / JQ, tid % JQ), JQ = T / NR lanes per row, holds
+// columns [jq*JS, (jq+1)*JS), JS = NP / JQ, of row rb*NR + il.
+#pragma once
+#include "kr_device.h"
+
+template <int NP, int NR, int LMAX>
+struct KrGeomR {
+    // NR = 64: 1024 threads (4 waves/SIMD, 128-VGPR budget, H(eps) block = 4*JS = 64 VGPRs); with 512 threads the
+    // block alone takes 128 of 256 VGPRs and the kernel spills (measured: 8.0k cycles per row-dot round)
+    static constexpr int THREADS = 512;  // (1024 threads for NR = 64 were measured slower: 67 vs 55 us per step at C5)
+    static constexpr int JQ = THREADS / NR;
+    static constexpr int JS = NP / JQ;
+    static constexpr int R = NP / NR;
+    static constexpr int NPP = NP + JQ;
+    // columns of the thread's H(eps) slice kept in registers / in LDS.  NR = 64 at NP = 256 has JS = 32 (128 VGPRs for
+    // the slice alone): hipcc then keeps part of it in scratch (measured 8.0k cycles per row-dot round), so the second
+    // half lives in LDS instead (16 * 512 * 16 B = 128 KB of the CU's 160 KB), thread-major and conflict-free.
+    static constexpr int JSR = (JS > 16) ? 16 : JS;
+    static constexpr int JSL = JS - JSR;
+    static constexpr int CHUNK = (JS >= 16) ? 4 : ((JS >= 8) ? 8 : JS);  // columns per streamed chunk (register budget: the H(eps) block takes 4*JS VGPRs)
+    static_assert(NR == 8 || NR == 16 || NR == 32 || NR == 64, "NR in {8,16,32,64}");
+    static_assert(NP == 128 || NP == 256, "NP in {128,256}");
+    static_assert(JS >= 2, "at least two columns per thread");
+};
+
+// sum over the JQ consecutive lanes of a row (JQ in {8,16,32,64}); every lane gets the sum
+template <int JQ>
+__device__ __forceinline__ double kr_row_sum_wide(double v) {
+    v += kr_dpp_mov<0xB1>(v);
+    v += kr_dpp_mov<0x4E>(v);
+    v += kr_dpp_mov<0x141>(v);              // 8 lanes
+    if (JQ >= 16) v += kr_dpp_mov<0x140>(v);  // row_mirror: 16 lanes
+    if (JQ >= 32) v += __shfl_xor(v, 16, 64);
+    if (JQ >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+typedef unsigned int kr_u4 __attribute__((ext_vector_type(4)));
+
+struct KrGroupBox {
+    unsigned long long *base;  // this tile's mailbox: [2][NP][4] granules
+    unsigned tag_base;
+    unsigned counter;
+};
+
+// Publish this workgroup's NR new elements (row owners hold them) and gather the other blocks of the tile into
+// the LDS vector `dst` (padded layout).  Returns false on abort.  All threads of the workgroup call it.
+template <int NP, int NR, int JS>
+__device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox &box, const int rb, const bool owner,
+                                                const int il, const double vr, const double vi, double2 *dst,
+                                                int *sflag) {
+    const int tid = threadIdx.x;
+    const unsigned tag = box.tag_base + (++box.counter);
+    const int par = box.counter & 1;
+    kr_gu64 *mb = (kr_gu64 *)(box.base + (size_t)par * NP * 4);
+    if (owner) {
+        const int e = rb * NR + il;
+        const unsigned long long br = (unsigned long long)__double_as_longlong(vr), bi = (unsigned long long)__double_as_longlong(vi);
+        const unsigned long long t = (unsigned long long)tag << 32;
+        __hip_atomic_store(mb + 4 * e + 0, t | (br & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mb + 4 * e + 1, t | (br >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mb + 4 * e + 2, t | (bi & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mb + 4 * e + 3, t | (bi >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dst[e + e / JS] = make_double2(vr, vi);  // own block goes straight to LDS
+    }
+    // wave 0 gathers the NP - NR foreign elements: lane handles elements lane, lane + 64, ...; every load of a pass
+    // is in flight before the first tag is looked at (no workgroup barrier inside the spin)
+    bool alive = true;
+    if ((tid >> 6) == 0) {
+        constexpr int EC = (NP - NR + 63) / 64;
+        const int lane = tid & 63;
+        int el[EC];
+#pragma unroll
+        for (int c = 0; c < EC; ++c) {
+            int q = min(lane + 64 * c, NP - NR - 1);
+            if (q >= rb * NR) q += NR;
+            el[c] = q;
+        }
+        unsigned long long g[EC][4];
+        const unsigned long long t0 = kr_realtime();
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) g[c][w] = __hip_atomic_load(mb + 4 * el[c] + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) ok = ok & ((unsigned)(g[c][w] >> 32) == tag);
+            }
+            if (__all(ok)) break;
+            if ((++spins & 63u) == 0u) {
+                const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (st != 0u || kr_realtime() - t0 > KR_SPIN_TIMEOUT_TICKS) {
+                    if (lane == 0 && st == 0u) {
+                        __hip_atomic_store((kr_gu32 *)a.status + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((kr_gu32 *)a.status + 2, box.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((kr_gu32 *)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    alive = false;
+                    break;
+                }
+            }
+        }
+        if (alive) {
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                if (lane + 64 * c < NP - NR) {
+                    const double re = __longlong_as_double((long long)((g[c][1] << 32) | (g[c][0] & 0xffffffffull)));
+                    const double im = __longlong_as_double((long long)((g[c][3] << 32) | (g[c][2] & 0xffffffffull)));
+                    dst[el[c] + el[c] / JS] = make_double2(re, im);
+                }
+            }
+        }
+        if (lane == 0) sflag[par] = alive ? 0 : 1;   // two slots by parity: the next gather writes the other one
+    }
+    __syncthreads();
+    const bool dead = (sflag[par] != 0);
+    return !dead;
+}
+
+// One streamed pass over this workgroup's blocks of H0, H_1..H_L (thread-major, [m][jj][rb][tid]):
+//   MODE 0 (known sweeps): Heps = H0 + sum e_l H_l
+//   MODE 1 (update, phase A): Heps = H0 + sum e_l H_l, b = Heps x, a_l = H_l x        (x = LDS vector, padded)
+//   MODE 2 (update, correction): Heps += sum e_l H_l                                   (e = delta eps)
+template <int NP, int NR, int LMAX, int MODE>
+__device__ __forceinline__ void kr_rs_stream(const __amdgpu_buffer_rsrc_t rsrc, const int rb, const int L, const double (&e)[LMAX],
+                                             double (&Er)[KrGeomR<NP, NR, LMAX>::JSR], double (&Ei)[KrGeomR<NP, NR, LMAX>::JSR],
+                                             double2 *sHl /* LDS part [JSL][512], or unused */,
+                                             const double2 *xp, double (&outr)[1 + LMAX], double (&outi)[1 + LMAX]) {
+    using G = KrGeomR<NP, NR, LMAX>;
+    constexpr int JS = G::JS, JSR = G::JSR, R = G::R, T = G::THREADS, JQ = G::JQ;
+    constexpr int CH = (MODE == 1 && G::CHUNK > 2 && JS >= 16) ? 2 : G::CHUNK;  // phase A carries 4(1+L) accumulators: smaller chunks
+    const int tid = threadIdx.x;
+    double ar[1 + LMAX], br[1 + LMAX], ai[1 + LMAX], bi[1 + LMAX];
+#pragma unroll
+    for (int o = 0; o <= LMAX; ++o) { ar[o] = 0; br[o] = 0; ai[o] = 0; bi[o] = 0; }
+#pragma unroll
+    for (int j0 = 0; j0 < JS; j0 += CH) {
+        double2 h[LMAX + 1][CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+#pragma unroll
+            for (int m = (MODE == 2 ? 1 : 0); m <= LMAX; ++m) {
+                h[m][u] = make_double2(0.0, 0.0);
+                if (m <= L) {
+                    // buffer load: resource (SGPRs) + one per-lane byte offset + a scalar offset per element.  With
+                    // flat/global addressing hipcc hoists 96 per-load 64-bit addresses out of the step loop and
+                    // spills them (368 VGPRs of scratch at NR = 64).
+                    const unsigned soff = (unsigned)((((m * JS + j0 + u) * R + rb) * T) * 16);
+                    const kr_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, soff, 0);
+                    double2 d;
+                    __builtin_memcpy(&d, &raw, 16);
+                    h[m][u] = d;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int jj = j0 + u;
+            double cr, ci;
+            if (MODE == 2) {
+                if (jj < JSR) { cr = Er[jj < JSR ? jj : 0]; ci = Ei[jj < JSR ? jj : 0]; }
+                else { const double2 o = sHl[(jj - JSR) * T + tid]; cr = o.x; ci = o.y; }
+            } else { cr = h[0][u].x; ci = h[0][u].y; }
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) { cr = fma(e[l], h[1 + l][u].x, cr); ci = fma(e[l], h[1 + l][u].y, ci); }
+            if (jj < JSR) { Er[jj < JSR ? jj : 0] = cr; Ei[jj < JSR ? jj : 0] = ci; }
+            else sHl[(jj - JSR) * T + tid] = make_double2(cr, ci);
+            if (MODE == 1) {
+                const double2 x = xp[j0 + u];
+                ar[0] = fma(cr, x.x, ar[0]); br[0] = fma(ci, x.y, br[0]);
+                ai[0] = fma(cr, x.y, ai[0]); bi[0] = fma(ci, x.x, bi[0]);
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    if (l < L) {
+                        const double2 hl = h[1 + l][u];
+                        ar[1 + l] = fma(hl.x, x.x, ar[1 + l]); br[1 + l] = fma(hl.y, x.y, br[1 + l]);
+                        ai[1 + l] = fma(hl.x, x.y, ai[1 + l]); bi[1 + l] = fma(hl.y, x.x, bi[1 + l]);
+                    }
+                }
+            }
+        }
+        if (NR >= 32) __builtin_amdgcn_sched_barrier(0);  // keep the loads of later chunks out of this one (registers)
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int o = 0; o <= LMAX; ++o) {
+            outr[o] = kr_row_sum_wide<JQ>(ar[o] - br[o]);
+            outi[o] = kr_row_sum_wide<JQ>(ai[o] + bi[o]);
+        }
+    }
+}
+
+// row dot with this thread's slice of H(eps): columns [0, JSR) from registers, [JSR, JS) from LDS (thread-major)
+template <int JS, int JSR, int JQ, int CH, int T>
+__device__ __forceinline__ void kr_rs_row_dot(const double (&Er)[JSR], const double (&Ei)[JSR], const double2 *sHl,
+                                              const double2 *xp, double &sr, double &si) {
+    const int tid = threadIdx.x;
+    double a = 0, b = 0, c = 0, d = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < JS; j0 += CH) {
+        double2 x[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) x[u] = xp[j0 + u];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int jj = j0 + u;
+            double hr, hi;
+            if (jj < JSR) { hr = Er[jj < JSR ? jj : 0]; hi = Ei[jj < JSR ? jj : 0]; }
+            else { const double2 o = sHl[(jj - JSR) * T + tid]; hr = o.x; hi = o.y; }
+            a = fma(hr, x[u].x, a); b = fma(hi, x[u].y, b);
+            c = fma(hr, x[u].y, c); d = fma(hi, x[u].x, d);
+        }
+        if (CH <= 4) __builtin_amdgcn_sched_barrier(0);
+    }
+    sr = kr_row_sum_wide<JQ>(a - b);
+    si = kr_row_sum_wide<JQ>(c + d);
+}
+
+// =============================================================================================
+template <int NP, int NR, int LMAX, bool UPDATE>
+__global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, LMAX>::THREADS / 256)) void kr_rowsplit_sweep(const KrSweepArgs a) {
+    using G = KrGeomR<NP, NR, LMAX>;
+    constexpr int JS = G::JS, JSR = G::JSR, JSL = G::JSL, JQ = G::JQ, R = G::R, NPP = G::NPP;
+    __shared__ __attribute__((aligned(16))) double2 sHl[JSL > 0 ? JSL * G::THREADS : 1];  // LDS part of the H(eps) block
+    __shared__ __attribute__((aligned(16))) double2 sx[2][NPP];   // full state vector psi (or chi), by step parity
+    __shared__ __attribute__((aligned(16))) double2 sy[2][NPP];   // Horner vectors, ping-pong
+    __shared__ double spart[LMAX * NR];
+    __shared__ double stot[LMAX + 1];
+    __shared__ int sflag[2];
+
+    const int tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63;
+    const int tile = wg / R, rb = wg % R;
+    const int il = tid / JQ, jq = tid % JQ;
+    const int row = rb * NR + il;
+    const bool owner = (jq == 0), row_ok = (row < a.N);
+    const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
+    const double my_thr = kr_load_my_thr(a);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[tile] : 0);
+    const int xoff = jq * (JS + 1);
+    const int N = a.N, NT = a.NT, L = a.L;
+    const size_t slab = (size_t)a.Kp * N;
+    const size_t kbase = (size_t)tile * N;
+
+    // generator blocks are read through a buffer resource (raw buffer loads, see kr_rs_stream)
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gx.Hpack, 0, (int)(a.pack_stride * 16), 0x00020000);
+    KrGroupBox box;
+    box.base = a.gmail + (size_t)tile * 2 * NP * 4;
+    box.tag_base = a.epoch_base2;
+    box.counter = 0;
+
+    // full initial vector into LDS, own element into registers
+    for (int e = tid; e < NP; e += G::THREADS) {
+        double2 v = make_double2(0.0, 0.0);
+        if (e < N) v = a.init[kbase + e];
+        sx[0][e + e / JS] = v;
+    }
+    double pr = 0.0, pim = 0.0, cr = 0.0, ci = 0.0;
+    if (row_ok) {
+        const double2 v = a.init[kbase + row];
+        pr = v.x; pim = v.y;
+        if (UPDATE) { const double2 c = a.X[kbase + row]; cr = c.x; ci = c.y; }
+        if (a.store && owner) a.store[(size_t)((a.dir > 0) ? 0 : NT) * slab + kbase + row] = v;
+    }
+    double gint[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) gint[l] = 0.0;
+    __syncthreads();
+
+    const bool stamp = (a.debug != nullptr) && (wg == 0);
+    unsigned long long tS = 0, tD = 0, tG = 0, tX = 0, t_prev = 0, nG = 0;
+    if (stamp) t_prev = __builtin_amdgcn_s_memtime();
+#define KR_STAMP(acc) if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - t_prev; t_prev = t_; }
+    double Er[JSR], Ei[JSR];
+    int cur = 0;
+    for (int step = 0; step < NT; ++step) {
+        const int n = (a.dir > 0) ? step : (NT - 1 - step);
+        const double dtn = a.dt[n];
+        const double sdt = (a.dir > 0) ? dtn : -dtn;
+        double e[LMAX], eg[LMAX], de[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { eg[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0; e[l] = eg[l]; de[l] = 0.0; }
+        double orr[1 + LMAX], oi[1 + LMAX];
+        if (!UPDATE) {
+            kr_rs_stream<NP, NR, LMAX, 0>(hrsrc, rb, L, eg, Er, Ei, sHl, nullptr, orr, oi);
+            KR_STAMP(tS)
+        } else {
+            // phase A: H(eps_guess) block into registers, b = H(eps_g) psi, a_l = H_l psi for the own rows
+            kr_rs_stream<NP, NR, LMAX, 1>(hrsrc, rb, L, eg, Er, Ei, sHl, &sx[cur][xoff], orr, oi);
+            KR_STAMP(tS)
+            double part[LMAX], du[LMAX];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                part[l] = 0.0;
+                if (l < L && ((gx.present >> l) & 1u)) part[l] = cr * oi[1 + l] - ci * orr[1 + l];
+            }
+            if (n + 1 < NT && row_ok) { const double2 c = a.X[(size_t)(n + 1) * slab + kbase + row]; cr = c.x; ci = c.y; }
+            if (!kr_exchange<LMAX, NR>(a, n, wg, owner, il, part, du, spart, stot)) return;
+            KR_STAMP(tX)
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l < L) {
+                    const double alpha = a.alpha[(size_t)l * NT + n];
+                    e[l] = __dadd_rn(eg[l], __dmul_rn(alpha, du[l]));
+                    de[l] = e[l] - eg[l];
+                    const double ad = fabs(du[l]);
+                    gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dtn));
+                    if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = e[l];
+                }
+            }
+            // H(eps_new) = H(eps_g) + sum_l d eps_l H_l  (second streamed pass over the control blocks only)
+            kr_rs_stream<NP, NR, LMAX, 2>(hrsrc, rb, L, de, Er, Ei, sHl, nullptr, orr, oi);
+            KR_STAMP(tS)
+        }
+        double theta = gx.nrm[0];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) theta += fabs(e[l]) * gx.nrm[1 + l];
+        theta *= fabs(sdt);
+        int s, m;
+        kr_plan_fast(a, my_thr, theta, s, m);
+        const double fs = (s == 1) ? sdt : sdt / (double)s;
+
+        for (int sub = 0; sub < s; ++sub) {
+            // Horner: y_m = x0 ... ; with the phase-A product known (update sweep, first sub-step) the constant is
+            // v = -i fs H psi and the result is psi + y_1; otherwise x0 = psi and the result is y_0.
+            const bool have_v = UPDATE && (sub == 0);
+            double x0r, x0i;
+            int w = 0, jlast;
+            const double2 *src;
+            if (have_v) {
+                double wr = orr[0], wi = oi[0];
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) { wr = fma(de[l], orr[1 + l], wr); wi = fma(de[l], oi[1 + l], wi); }
+                x0r = fs * wi; x0i = -fs * wr;
+                if (m > 1) { if (!kr_group_gather<NP, NR, JS>(a, box, rb, owner, il, x0r, x0i, sy[0], sflag)) return; }
+                w = 1; jlast = 2; src = sy[0];
+            } else {
+                x0r = pr; x0i = pim; jlast = 1; src = sx[cur];
+            }
+            double yr = x0r, yi = x0i;
+            for (int j = m; j >= jlast; --j) {
+                const double f = fs * kr_rinv_lane(my_rinv, j);
+                double sr, si;
+                kr_rs_row_dot<JS, JSR, JQ, (JS >= 8 ? 8 : JS), G::THREADS>(Er, Ei, sHl, src + xoff, sr, si);
+                yr = fma(f, si, x0r);
+                yi = fma(-f, sr, x0i);
+                const bool last = (j == jlast);
+                if (last && have_v) { yr += pr; yi += pim; }   // psi' = psi + y_1
+                double2 *dst = last ? sx[cur ^ 1] : sy[w];
+                KR_STAMP(tD)
+                if (!kr_group_gather<NP, NR, JS>(a, box, rb, owner, il, yr, yi, dst, sflag)) return;
+                KR_STAMP(tG)
+                nG++;
+                src = sy[w];
+                w ^= 1;
+            }
+            if (have_v && m == 1) {  // psi' = psi + v : no round ran
+                yr = pr + x0r; yi = pim + x0i;
+                if (!kr_group_gather<NP, NR, JS>(a, box, rb, owner, il, yr, yi, sx[cur ^ 1], sflag)) return;
+            }
+            pr = yr; pim = yi;
+            cur ^= 1;
+        }
+        if (a.store && owner && row_ok) {
+            const int slot = (a.dir > 0) ? (n + 1) : n;
+            a.store[(size_t)slot * slab + kbase + row] = make_double2(pr, pim);
+        }
+    }
+    if (stamp && tid == 0) { a.debug[0] = tS; a.debug[1] = tD; a.debug[2] = tG; a.debug[3] = tX; a.debug[7] = nG; }
+#undef KR_STAMP
+    if (a.fin && owner && row_ok) a.fin[kbase + row] = make_double2(pr, pim);
+    if (UPDATE && wg == 0 && tid == 0) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
+    }
+}
+
+// kind: 0 known sweep, 1 update sweep; nr = rows per workgroup
+template <int NP>
+static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
+#define KR_CASE_R(LM, NRv)                                                                             \
+    if (lmax == LM && nr == NRv) {                                                                     \
+        if (kind == 0) hipLaunchKernelGGL((kr_rowsplit_sweep<NP, NRv, LM, false>), dim3(grid), dim3(KrGeomR<NP, NRv, LM>::THREADS), 0, s, *a); \
+        else hipLaunchKernelGGL((kr_rowsplit_sweep<NP, NRv, LM, true>), dim3(grid), dim3(KrGeomR<NP, NRv, LM>::THREADS), 0, s, *a);             \
+        return hipGetLastError();                                                                      \
+    }
+    KR_CASE_R(2, 8) KR_CASE_R(2, 16) KR_CASE_R(2, 32) KR_CASE_R(2, 64)
+    KR_CASE_R(4, 8) KR_CASE_R(4, 16) KR_CASE_R(4, 32) KR_CASE_R(4, 64)
+#undef KR_CASE_R
+    return hipErrorInvalidValue;
+}

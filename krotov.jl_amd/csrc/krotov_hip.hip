@@ -35,6 +35,13 @@ struct kr_handle {
     // plan
     int NP = 0, LMAXv = 0, KT = 0, SG = 0, KTILE = 0, P = 0, Kp = 0, threads = 0, JQ = 4, JS = 0, RT = 0;
     kr_launch_fn launch = nullptr;
+    // row-split mode (64 < N <= 256): R workgroups of 512 threads share one trajectory (kr_device_rowsplit.h)
+    bool rowsplit = false;
+    int R = 1, NR = 0;
+    kr_launch_fn launch_rs = nullptr;
+    unsigned long long *gmail_d = nullptr;
+    size_t gmail_words = 0;
+    unsigned launch_id = 0;
     bool store_fw = true;
     double tol = 1e-16;
     double thr[KR_MAX_ORDER]{};
@@ -147,6 +154,21 @@ static void pack_generator(int N, int NP, int JQ, const zc *M, bool adj, double2
             }
 }
 
+// Row-split pack: out[((jj)*R + rb)*T + il*JQ + jq] = M[rb*NR + il][jq*JS + jj]  (one matrix; zero outside N)
+static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj, double2 *out) {
+    const int T = 512;
+    const int R = NP / NR, JQ = T / NR, JS = NP / JQ;
+    for (int jj = 0; jj < JS; ++jj)
+        for (int rb = 0; rb < R; ++rb)
+            for (int il = 0; il < NR; ++il)
+                for (int jq = 0; jq < JQ; ++jq) {
+                    const int i = rb * NR + il, j = jq * JS + jj;
+                    zc v = 0;
+                    if (i < N && j < N) v = adj ? std::conj(M[j + (size_t)i * N]) : M[i + (size_t)j * N];
+                    out[((size_t)jj * R + rb) * T + il * JQ + jq] = make_double2(v.real(), v.imag());
+                }
+}
+
 static int env_int(const char *name, int dflt) {
     const char *s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
@@ -226,6 +248,31 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
     int cus = prop.multiProcessorCount;
     int maxwg = env_int("KROTOV_HIP_MAX_WG", cus);  // one persistent workgroup per CU
     if (maxwg < 1) maxwg = 1;
+    if (NP > 64 && env_int("KROTOV_HIP_ROWSPLIT", 1) != 0) {
+        // R workgroups per trajectory, NR = NP / R rows each (8 <= NR <= 64: the H(eps) block must fit the registers)
+        int R = NP / 64;
+        if ((long long)c.K * R <= maxwg) {
+            while (NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
+            h->rowsplit = true;
+            h->R = R;
+            h->NR = NP / R;
+            h->threads = 512;  // mirrors KrGeomR
+            h->JQ = h->threads / h->NR;
+            h->JS = NP / h->JQ;
+            h->RT = h->threads;
+            h->SG = 1;
+            h->launch_rs = (NP == 128) ? kr_launch_rs128 : kr_launch_rs256;
+            h->KT = 1;
+            h->KTILE = 1;
+            h->P = c.K * R;
+            h->Kp = c.K;
+            h->perm.assign(c.K, 0);
+            wg_gen.assign(c.K, 0);
+            for (int k = 0; k < c.K; ++k) { h->perm[k] = k; wg_gen[k] = tg ? tg[k] : 0; }
+            h->identity_perm = true;
+            return KR_OK;
+        }
+    }
     int kt = env_int("KROTOV_HIP_KT", 0);
     if (kt != 0 && kt != 1 && kt != 2 && kt != 4) return fail(h, KR_ERR_INVALID, "KROTOV_HIP_KT must be 1, 2 or 4");
     // trajectories per generator (tiles never mix generators)
@@ -272,7 +319,7 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
-                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d};
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -361,7 +408,7 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     const zc *H0 = (const zc *)cfg->H0, *Hc = (const zc *)cfg->Hc;
     std::vector<double> nrm((size_t)G * (1 + KR_LMAX_CAP), 0.0);
     std::vector<unsigned> present(G, 0u);
-    h->pack_stride = (size_t)(1 + L) * h->JS * h->RT;
+    h->pack_stride = (size_t)(1 + L) * NP * NP;  // = (1+L) * JS * RT in every geometry
     const size_t pack_elems = h->pack_stride * G;
     std::vector<double2> pack(pack_elems);
     CHK(dalloc(&h->Hpack_fw, pack_elems));
@@ -376,16 +423,25 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     for (int adj = 0; adj < 2; ++adj) {
         for (int g = 0; g < G; ++g)
             for (int m = 0; m <= L; ++m)
-                pack_generator(N, NP, h->JQ, m == 0 ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn, adj != 0,
-                               pack.data() + (size_t)g * h->pack_stride + (size_t)m * h->JS * h->RT);
+            {
+                const zc *M = (m == 0) ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn;
+                double2 *dst = pack.data() + (size_t)g * h->pack_stride + (size_t)m * NP * NP;
+                if (h->rowsplit) pack_generator_rowsplit(N, NP, h->NR, M, adj != 0, dst);
+                else pack_generator(N, NP, h->JQ, M, adj != 0, dst);
+            }
         CHK(hipMemcpy(adj ? h->Hpack_bw : h->Hpack_fw, pack.data(), pack_elems * sizeof(double2), hipMemcpyHostToDevice));
     }
     CHK(dalloc(&h->nrm_d, nrm.size()));
     CHK(hipMemcpy(h->nrm_d, nrm.data(), nrm.size() * sizeof(double), hipMemcpyHostToDevice));
     CHK(dalloc(&h->present_d, (size_t)G));
     CHK(hipMemcpy(h->present_d, present.data(), G * sizeof(unsigned), hipMemcpyHostToDevice));
-    CHK(dalloc(&h->wg_gen_d, (size_t)h->P));
-    CHK(hipMemcpy(h->wg_gen_d, wg_gen.data(), h->P * sizeof(int), hipMemcpyHostToDevice));
+    CHK(dalloc(&h->wg_gen_d, wg_gen.size()));
+    CHK(hipMemcpy(h->wg_gen_d, wg_gen.data(), wg_gen.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (h->rowsplit) {
+        h->gmail_words = (size_t)cfg->K * 2 * NP * 4;
+        CHK(dalloc(&h->gmail_d, h->gmail_words));
+        CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
+    }
     std::vector<double> dt(NT);
     for (int n = 0; n < NT; ++n) dt[n] = cfg->tlist[n + 1] - cfg->tlist[n];
     CHK(dalloc(&h->dt_d, NT));
@@ -496,7 +552,7 @@ extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
     if (!h || !info) return KR_ERR_INVALID;
     memset(info, 0, 16 * sizeof(int32_t));
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
-    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0;
+    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0;
     // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
     return KR_OK;
 }
@@ -554,6 +610,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.tol = h->tol;
     memcpy(a.thr, h->thr, sizeof a.thr);
     a.use_mfma = h->use_mfma ? 1 : 0;
+    a.gmail = h->gmail_d;
     a.pack_stride = h->pack_stride;
     a.wg_gen = (h->G > 1) ? h->wg_gen_d : nullptr;
     a.nrm_dev = h->nrm_d;
@@ -563,6 +620,21 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.mail = h->mail_d;
     a.xmail = h->xmail_d;
     for (int r = 0; r < 8; ++r) a.peer_xmail[r] = h->peer_xmail[r];
+}
+
+// vector-mailbox tags of the row-split kernels: (launch id mod 4096) << 20 | gather counter; the mailbox is
+// cleared whenever the launch id wraps, and a launch may use at most 2^20 gathers (N_T * rounds per step)
+static int rowsplit_prelaunch(kr_handle *h, KrSweepArgs &a) {
+    if ((long long)h->cfg.NT * (KR_MAX_ORDER + 2) * 4 >= (1ll << 20))
+        return fail(h, KR_ERR_UNSUPPORTED, "row-split kernels: N_T = %d too large for the mailbox tag space", h->cfg.NT);
+    h->launch_id = (h->launch_id + 1) & 0xfffu;
+    if (h->launch_id == 0) {
+        HIPCHK(h, hipMemsetAsync(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long), h->stream));
+        h->launch_id = 1;
+    }
+    a.epoch_base2 = h->launch_id << 20;
+    HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
+    return KR_OK;
 }
 
 static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool backward, const double2 *init, double2 *store, double2 *fin) {
@@ -575,7 +647,11 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     a.U = h->U_d;
     int rc = ev_mark(h, which_ev, false);
     if (rc) return rc;
-    if (h->precomp) {
+    if (h->rowsplit) {
+        rc = rowsplit_prelaunch(h, a);
+        if (rc) return rc;
+        HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 0, h->P, h->stream, &a));
+    } else if (h->precomp) {
         // all N_T step propagators in parallel, then one matvec round per step
         HIPCHK(h, h->launch(h->LMAXv, h->KT, 2, h->cfg.NT * h->G, h->stream, &a));
         // The apply sweep is bound by streaming U_n (NP^2 * 16 B per workgroup per step) from L2: with a shared
@@ -612,6 +688,11 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
     int rc = ev_mark(h, 2, false);
     if (rc) return rc;
+    if (h->rowsplit) {
+        rc = rowsplit_prelaunch(h, a);
+        if (rc) return rc;
+        HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 1, h->P, h->stream, &a));
+    } else
     HIPCHK(h, h->launch(h->LMAXv, h->KT, 1, h->P, h->stream, &a));
     return ev_mark(h, 2, true);
 }

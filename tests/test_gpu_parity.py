@@ -229,15 +229,30 @@ def test_full_size_properties_c3():
         assert J[3] < J[2] < J[1] < J[0]
 
 
-def test_streamed_generator_sizes(oracle_c):
-    """64 < N <= 256: the streamed-generator kernels (kr_device_stream.h), Hermitian and Liouvillian."""
-    for (N, NT, K, L, seed) in [(65, 6, 2, 1, 41), (100, 5, 3, 2, 42), (128, 4, 2, 1, 43), (200, 3, 2, 3, 44)]:
+@pytest.mark.parametrize("rowsplit", ["1", "0"])
+def test_large_state_dimension(oracle_c, monkeypatch, rowsplit):
+    """64 < N <= 256, Hermitian and Liouvillian: row-split kernels (R workgroups share a trajectory and all-gather
+    the vector after every matvec round, kr_device_rowsplit.h) and the one-workgroup-per-trajectory streamed
+    kernels (kr_device_stream.h)."""
+    monkeypatch.setenv("KROTOV_HIP_ROWSPLIT", rowsplit)
+    for (N, NT, K, L, seed) in [(65, 6, 2, 1, 41), (100, 5, 3, 2, 42), (128, 4, 2, 1, 43), (200, 3, 2, 3, 44),
+                                (130, 3, 40, 1, 45), (256, 3, 60, 2, 46), (256, 2, 70, 1, 48)]:
         p = wl.dense_problem(N, NT, K, L, seed, 0.05, 2.0)
-        info = _run_case(oracle_c, p)
+        info = _run_case(oracle_c, p, check_storage=(K < 10))
         assert info["NP"] in (128, 256)
+        fits = K * (info["NP"] // 64) <= 256   # K = 70 at NP = 256 needs 280 workgroups: streamed kernels take over
+        assert (info["rowsplit_R"] > 0) == (rowsplit == "1" and fits)
     p = wl.liouvillian_problem(n_levels=16, NT=4, K=3, seed=256001)   # C5's operators, short grid
     info = _run_case(oracle_c, p)
     assert info["NP"] == 256
+
+
+def test_rowsplit_with_substeps_and_generators(oracle_c):
+    """Row-split kernels with ||H dt|| > 1 (sub-stepping: every sub-step gathers) and G > 1."""
+    p = wl.dense_problem(96, 4, 3, 1, 47, 0.1, 50.0)
+    p["H0"] = p["H0"] * 25.0
+    info = _run_case(oracle_c, p)
+    assert info["rowsplit_R"] > 0
 
 
 def test_unsupported_sizes_fail_loudly():

@@ -39,3 +39,6 @@ if st[4]:
 if st[5]:
     print("  taylor phase split (wg 0): setup until first round %.0f, rounds %.0f, finalize %.0f cycles/step"
           % (st[5] / NT, (st[6] - st[5]) / NT, (st[2] - st[6]) / NT))
+if eng.info().get("rowsplit_R", 0) and st[7]:
+    print("  row-split stamps (wg 0, last sweep): stream %.0f cycles/step, row-dot %.0f and gather %.0f cycles/round, exchange %.0f cycles/step, %d rounds"
+          % (st[0] / NT, st[1] / st[7], st[2] / st[7], st[3] / NT, st[7]))
