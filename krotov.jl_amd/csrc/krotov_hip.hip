@@ -251,7 +251,7 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
     if (NP > 64 && env_int("KROTOV_HIP_ROWSPLIT", 1) != 0) {
         // R workgroups per trajectory, NR = NP / R rows each (8 <= NR <= 64: the H(eps) block must fit the registers)
         int R = NP / 64;
-        if ((long long)c.K * R <= maxwg) {
+        if ((long long)c.K * R <= maxwg && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
             while (NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
             h->rowsplit = true;
             h->R = R;
@@ -622,17 +622,17 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     for (int r = 0; r < 8; ++r) a.peer_xmail[r] = h->peer_xmail[r];
 }
 
-// vector-mailbox tags of the row-split kernels: (launch id mod 4096) << 20 | gather counter; the mailbox is
-// cleared whenever the launch id wraps, and a launch may use at most 2^20 gathers (N_T * rounds per step)
+// vector-mailbox tags of the row-split kernels: (launch id mod 256) << 24 | gather counter; the mailbox is cleared
+// whenever the launch id wraps, and a launch may use at most 2^24 gathers (N_T * rounds per step)
 static int rowsplit_prelaunch(kr_handle *h, KrSweepArgs &a) {
-    if ((long long)h->cfg.NT * (KR_MAX_ORDER + 2) * 4 >= (1ll << 20))
-        return fail(h, KR_ERR_UNSUPPORTED, "row-split kernels: N_T = %d too large for the mailbox tag space", h->cfg.NT);
-    h->launch_id = (h->launch_id + 1) & 0xfffu;
+    if ((long long)h->cfg.NT * (KR_MAX_ORDER + 2) * 4 >= (1ll << 24))
+        return fail(h, KR_ERR_UNSUPPORTED, "row-split kernels: N_T = %d too large for the mailbox tag space (set KROTOV_HIP_ROWSPLIT=0)", h->cfg.NT);
+    h->launch_id = (h->launch_id + 1) & 0xffu;
     if (h->launch_id == 0) {
         HIPCHK(h, hipMemsetAsync(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long), h->stream));
         h->launch_id = 1;
     }
-    a.epoch_base2 = h->launch_id << 20;
+    a.epoch_base2 = h->launch_id << 24;
     HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
     return KR_OK;
 }

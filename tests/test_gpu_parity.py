@@ -375,3 +375,18 @@ def test_n64_large_norm_scaling_and_squaring(oracle_c, monkeypatch):
     for mfma in ("1", "0"):
         monkeypatch.setenv("KROTOV_HIP_EXPM_MFMA", mfma)
         _run_case(oracle_c, p, check_storage=True)
+
+
+def test_rowsplit_mailbox_tag_wrap(oracle_c):
+    """More than 256 launches on one handle: the row-split vector mailbox's launch tag wraps and the mailbox is
+    cleared; results must stay identical from launch to launch."""
+    p = wl.dense_problem(70, 3, 2, 1, 49, 0.05, 2.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 2) as eng:
+        assert eng.info()["rowsplit_R"] > 0
+        eng.set_initial_states(p["psi0"])
+        first = eng.forward(p["eps"])
+        for _ in range(300):
+            again = eng.forward(p["eps"])
+        assert np.array_equal(again, first)
+    psiT_o, _ = oracle_c.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False)
+    assert np.max(np.abs(first - psiT_o)) < TOL_STATE
