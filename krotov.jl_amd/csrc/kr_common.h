@@ -44,7 +44,6 @@ struct KrSweepArgs {
     int P;                   // workgroups
     int rank, world;
     unsigned epoch_base;     // tags = epoch_base + n + 1
-    int n_begin, n_end;      // step range of this launch (update sweep may be split)
     int use_mfma;            // propagator build on the matrix cores where available (NP = 64)
 };
 

@@ -44,7 +44,6 @@ struct KrGeom {
     static constexpr int SG = THREADS / RT;
     static constexpr int KTILE = SG * KT;
     static constexpr int NPP = NP + JQ;  // one 16-B pad slot per column segment
-    static constexpr int HREG = H0LDS ? 0 : 1;  // first generator kept in registers (0: H0 in LDS)
     static_assert(NP >= 8 && NP <= 64 && (NP & (NP - 1)) == 0, "NP in {8,16,32,64}");
 };
 
