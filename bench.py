@@ -116,10 +116,30 @@ def main():
         q = wl.dense_problem(N, NT, K_local, L, 64001 + 1000 * rank, p["tlist"][1] - p["tlist"][0], p["lam"][0])
         p["psi0"], p["tgt"] = q["psi0"], q["tgt"]
 
-    eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K_local, device=local_rank, rank=rank, world=world,
-                       K_global=K_global)
+    parallelism = "trajectories sharded over %d GPU(s); per-step sum of %d doubles" % (world, L)
+    eng = None
     if world > 1:
-        krd.connect_peers(eng, dist)
+        # peer mailboxes over xGMI (IPC-mapped).  Every rank must succeed, otherwise ALL ranks fall back to
+        # independent replicas (no cross-GPU sum) and the JSON line says so.
+        ok = 1
+        try:
+            eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K_local, device=local_rank, rank=rank, world=world,
+                               K_global=K_global)
+            krd.connect_peers(eng, dist)
+        except Exception as exc:  # noqa: BLE001
+            log("rank %d: peer mailbox set-up failed: %r" % (rank, exc))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", local_rank))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if eng is not None:
+                eng.close()
+            eng = None
+            K_global = K_local
+            parallelism = ("REPLICAS ONLY: %d independent copies of the K=%d problem, no cross-GPU reduction "
+                           "(peer mailbox set-up failed)" % (world, K_local))
+    if eng is None:
+        eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K_local, device=local_rank, K_global=K_global)
     eng.set_initial_states(p["psi0"])
     eng.set_target_states(p["tgt"])
     eng.set_update_params(p["S"], p["lam"])
@@ -164,7 +184,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        units = 2.0 * K_global * NT            # one backward + one forward state-step per trajectory per interval
+        units = 2.0 * K_local * world * NT     # one backward + one forward state-step per trajectory per interval
         value = units * args.steps / elapsed
         # dominant kernel: the update sweep.  Algorithmic flops per (trajectory, interval) unit of that
         # kernel with a precomputed step propagator: forward apply 8N^2 + L mu-matvecs 8N^2 L
@@ -204,7 +224,7 @@ def main():
             "config": {"workload": "%s: N=%d dense Hermitian H0 + %d controls, N_T=%d, K=%d trajectories per GPU "
                                    "(K_global=%d), J_T_%s, lambda_a=%g; one Krotov iteration per step"
                                    % (args.config, N, L, NT, K_local, K_global, p["functional"], p["lam"][0]),
-                       "parallelism": "trajectories sharded over %d GPU(s); per-step sum of %d doubles" % (world, L),
+                       "parallelism": parallelism,
                        "engine": info},
             "roofline": {"bound": "mfma", "kernel": "kr_sweep_update", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
