@@ -53,6 +53,25 @@ class KrotovHipError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process, one HIP/HSA runtime.  PyTorch-ROCm bundles its own libamdhip64.so; libkrotov_hip.so names the
+    same soname.  If ours (from /opt/rocm) is loaded first and torch's copy later, the second runtime finds no GPU
+    ("No HIP GPUs are available").  So when torch is installed, its runtime is mapped first (without importing
+    torch) and libkrotov_hip.so binds to it; a later `import torch` then reuses the same mapping."""
+    if os.environ.get("KROTOV_HIP_SHARE_TORCH_RUNTIME", "1") == "0":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- fall back to the system runtime
+        pass
+
+
 def load():
     """dlopen the HIP engine; fails loudly when it has not been built."""
     global _lib
@@ -62,6 +81,7 @@ def load():
         raise KrotovHipError(KR_ERR_NO_DEVICE,
                              "%s not found -- build it with __graft_entry__.build() "
                              "(make -C krotov.jl_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     lib.kr_last_error.restype = C.c_char_p
     lib.kr_last_error.argtypes = [C.c_void_p]

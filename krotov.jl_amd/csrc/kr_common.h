@@ -7,6 +7,9 @@
 #define KR_LMAX_CAP 4           // largest L of the register-resident kernels
 #define KR_THETA_MAX 1.0        // largest ||H dt|| handled by one Taylor sub-step
 #define KR_MAX_ORDER 48
+#ifndef KR_APPLY_JQ64
+#define KR_APPLY_JQ64 8          // lanes per row of the apply sweep at NP = 64 (8: 512-thread workgroups)
+#endif
 #define KR_SPIN_TIMEOUT_TICKS 400000000ull  // 4 s of s_memrealtime (100 MHz): bounded spin
 
 // status words (device): [0] abort/timeout flag, [1] where, [2] step, [3] spare

@@ -779,7 +779,7 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
         if (kind == 0) hipLaunchKernelGGL((kr_sweep_known<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
         else if (kind == 1) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
         else if (kind == 2) { kr_launch_expm<NP, LM, CB>(grid, s, a); }                              \
-        else hipLaunchKernelGGL((kr_sweep_apply<NP, KTv>), dim3(grid), dim3(256), 0, s, *a);      \
+        else hipLaunchKernelGGL((kr_sweep_apply<NP, KTv>), dim3(grid), dim3(KrApplyGeom<NP>::THREADS), 0, s, *a);      \
         return hipGetLastError();                                                                 \
     }
     KR_CASE(2, 1) KR_CASE(2, 2) KR_CASE(2, 4)

@@ -12,13 +12,23 @@
 #pragma once
 // (included at the end of kr_device.h)
 
+// Geometry of the consumer kr_sweep_apply: lanes per row JQA (8 with 512-thread workgroups for NP = 64, else 4).
+// U_n is stored thread-major for it:  Upack[n][jj * (JQA*NP) + i*JQA + jq] = U_n[i][jq*(NP/JQA) + jj].
+template <int NP> struct KrApplyGeom {
+    static constexpr int JQA = (NP >= 64) ? KR_APPLY_JQ64 : 4;
+    static constexpr int JS = NP / JQA;
+    static constexpr int RT = NP * JQA;
+    static constexpr int THREADS = (RT > 256) ? RT : 256;
+    static constexpr int SG = THREADS / RT;
+};
+
 // ---- batched propagator construction -------------------------------------------------------------
 template <int NP, int LMAX, int CB>
 __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1>::THREADS / 256)) void kr_expm_batch(const KrSweepArgs a) {
     double2 *__restrict__ Upack = a.U;
     using G = KrGeom<NP, LMAX, 1>;
     constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, NPP = G::NPP;
-    constexpr int JS_A = NP / 4, RT_A = 4 * NP;  // geometry of the consumer (kr_sweep_apply)
+    constexpr int JS_A = KrApplyGeom<NP>::JS, RT_A = KrApplyGeom<NP>::RT, JQ_A = KrApplyGeom<NP>::JQA;  // consumer geometry
     __shared__ __attribute__((aligned(16))) double2 sy[2][SG * CB][NPP];
     __shared__ __attribute__((aligned(16))) double2 sH0[G::H0LDS ? JS * RT : 1];
 
@@ -98,7 +108,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
 #pragma unroll
             for (int b = 0; b < CB; ++b) {
                 const int c = cbase + b;
-                if (c < NP) Un[(size_t)(c % JS_A) * RT_A + i * 4 + (c / JS_A)] = make_double2(pr[b], pim[b]);
+                if (c < NP) Un[(size_t)(c % JS_A) * RT_A + i * JQ_A + (c / JS_A)] = make_double2(pr[b], pim[b]);
             }
         }
         __syncthreads();
@@ -107,9 +117,10 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
 
 // ---- known-pulse sweep with precomputed propagators: one round per step ---------------------------
 template <int NP, int KT>
-__global__ __launch_bounds__(256, 1) void kr_sweep_apply(const KrSweepArgs a) {
+__global__ __launch_bounds__((KrApplyGeom<NP>::THREADS), (KrApplyGeom<NP>::THREADS / 256)) void kr_sweep_apply(const KrSweepArgs a) {
     const double2 *__restrict__ Upack = a.U + (size_t)(a.wg_gen ? a.wg_gen[blockIdx.x] : 0) * a.NT * NP * NP;
-    constexpr int JQ = 4, JS = NP / 4, RT = 4 * NP, SG = 256 / RT, KTILE = SG * KT, NPP = NP + JQ, NW = 4;
+    using GA = KrApplyGeom<NP>;
+    constexpr int JQ = GA::JQA, JS = GA::JS, RT = GA::RT, SG = GA::SG, KTILE = SG * KT, NPP = NP + JQ, NW = GA::THREADS / 64;
     constexpr int CH = (KTILE * NP + 63) / 64;
     __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];
 
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
     // producer-side pack geometry (how Hpack was written for NP = 64, see KrGeom)
     using G = KrGeom<NP, LMAX, 1>;
     constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT;
-    constexpr int JS_A = NP / 4, RT_A = 4 * NP;
+    constexpr int JS_A = KrApplyGeom<NP>::JS, RT_A = KrApplyGeom<NP>::RT, JQ_A = KrApplyGeom<NP>::JQA;
     extern __shared__ __attribute__((aligned(16))) double kr_lds[];
     // planes: [buffer b][re | im][64][KR_YS]
 #define KR_YR(b) (kr_lds + (size_t)(b) * 2 * NP * KR_YS)
@@ -311,10 +322,12 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
     }
     // U_n -> thread-major pack of the apply kernel: Upack[jj * 256 + i*4 + jq] = U[i][jq*16 + jj]
     double2 *Un = a.U + ((size_t)gx.gen * NT + n) * NP * NP;
-    const int i = tid >> 2, jq = tid & 3;
+    for (int t2 = tid; t2 < RT_A; t2 += 256) {   // consumer thread t2 = (i, jq)
+        const int i = t2 / JQ_A, jq = t2 % JQ_A;
 #pragma unroll
-    for (int jj = 0; jj < JS_A; ++jj) {
-        const int c = jq * JS_A + jj;
-        Un[(size_t)jj * RT_A + tid] = make_double2(KR_YR(cur)[i * KR_YS + c], KR_YI(cur)[i * KR_YS + c]);
+        for (int jj = 0; jj < JS_A; ++jj) {
+            const int c = jq * JS_A + jj;
+            Un[(size_t)jj * RT_A + t2] = make_double2(KR_YR(cur)[i * KR_YS + c], KR_YI(cur)[i * KR_YS + c]);
+        }
     }
 }
