@@ -14,7 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _problem(which):
+    from krotov_jl_amd import workloads as wl
+    if which == "rowsplit":   # N = 80 -> NP = 128, row-split kernels (several workgroups per trajectory)
+        return wl.dense_problem(80, 8, 6, 1, 910, 0.05, 1.0), 6
+    return wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0), 24
+
+
+def _worker(rank, world, port, q, which="small"):
     sys.path.insert(0, ROOT)
     os.environ["KROTOV_HIP_MAX_WG"] = "64"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -25,8 +32,7 @@ def _worker(rank, world, port, q):
     from krotov_jl_amd.distributed import shard_range, connect_peers
     try:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        p = wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0)
-        K = 24
+        p, K = _problem(which)
         a, b = shard_range(K, rank, world)
         eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], b - a, device=0, rank=rank, world=world, K_global=K)
         connect_peers(eng, dist)
@@ -46,7 +52,8 @@ def _worker(rank, world, port, q):
         raise
 
 
-def test_two_ranks_one_gpu_equals_unsharded():
+@pytest.mark.parametrize("which", ["small", "rowsplit"])
+def test_two_ranks_one_gpu_equals_unsharded(which):
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
     import krotov_jl_amd as kr
@@ -54,7 +61,7 @@ def test_two_ranks_one_gpu_equals_unsharded():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, which)) for r in range(2)]
     for pr in procs:
         pr.start()
     got = {}
@@ -69,8 +76,8 @@ def test_two_ranks_one_gpu_equals_unsharded():
     assert np.array_equal(got[0][0], got[1][0])
     assert np.array_equal(got[0][1], got[1][1])
     # unsharded reference on one handle
-    p = wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0)
-    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 24) as eng:
+    p, K = _problem(which)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
         eng.set_initial_states(p["psi0"])
         psiT = eng.forward(p["eps"])
         eps = p["eps"].copy()
