@@ -1,19 +1,21 @@
 // Device code of the Krotov sweeps for gfx950 (CDNA4).  Register-resident-generator variant,
 // state dimension padded to NP in {8,16,32,64}.
 //
-// Mapping (one 256-thread workgroup per CU, persistent over all N_T time steps):
-//   team  = JQ*NP threads (JQ = 4, or 8 for NP = 64 where the workgroup has 512 threads) that own ONE copy of the generator slices H0, H_1..H_L in registers:
-//           thread (i, jq) holds row i, columns [jq*JS, (jq+1)*JS), JS = NP/4, of every matrix;
-//   a workgroup has SG = 256/(4*NP) teams; each team propagates KT trajectories, so one
-//   workgroup carries KTILE = SG*KT trajectories and the generator is read from HBM/L2 ONCE per
-//   sweep, not once per step.
-//   A matvec y = H x reads the x slice from LDS (16-B reads, broadcast across the rows of a
-//   wave, padded so the four column segments fall on different banks), does 4*JS fp64 FMAs per
-//   thread in four independent chains, and sums the four column segments of a row inside the
-//   lane quad with DPP (no LDS, no wave-wide shuffle).
-//   The step propagator exp(-i H(eps_n) dt) is never formed: it is applied as a Horner-form
-//   Taylor polynomial of order m (chosen per step from ||H(eps_n)|| dt so that the truncation
-//   bound is below tol), with H(eps_n) = H0 + sum_l eps_l[n] H_l combined in registers.
+// Mapping (one persistent workgroup per CU over all N_T time steps; 256 threads, 512 for NP = 64):
+//   team  = JQ*NP threads that own ONE copy of the generator slices in registers (JQ = 4; JQ = 8 for NP = 64):
+//           thread (i, jq) holds row i, columns [jq*JS, (jq+1)*JS), JS = NP/JQ, of every matrix
+//           (for NP = 64 and L <= 2 the drift slice H0 lives in LDS instead);
+//   a workgroup has SG = THREADS/(JQ*NP) teams; each team propagates KT trajectories, so one workgroup
+//   carries KTILE = SG*KT trajectories and the generator is read from HBM/L2 ONCE per sweep, not per step.
+//   A matvec round y = H x issues all JS 16-B LDS reads of the x slice back to back (broadcast across the
+//   rows of a wave, padded so the JQ column segments fall on different banks), does 4*JS fp64 FMAs per thread
+//   in four independent chains, and sums the JQ column segments of a row inside the lane group with DPP
+//   (no LDS, no wave-wide shuffle); one LDS write per row and one s_barrier end the round.
+//   In the update sweep the step propagator exp(-i H(eps_n) dt) is never formed: it is applied as a
+//   Horner-form Taylor polynomial of order m (chosen per step from ||H(eps_n)|| dt so that the truncation
+//   bound is below tol), with H(eps_n) = H0 + sum_l eps_l[n] H_l combined in registers.  The known-pulse
+//   sweeps normally run on precomputed propagators instead (kr_device_prop.h); kr_sweep_known is their
+//   Taylor form (KROTOV_HIP_PRECOMP=0, or when the propagator buffer would be too large).
 //
 // Reference semantics restated (paths under /root/reference):
 //   kr_sweep_known  : optimize.jl:247-265 (initial forward sweep) and :303-317 (backward sweep
