@@ -164,6 +164,7 @@ def main():
         eng.iteration_functional_dev(func, eps_a.data_ptr(), eps_b.data_ptr())
         eps_a, eps_b = eps_b, eps_a   # pulse ping-pong, optimize.jl:216
 
+    sync_all()   # all ranks enter the first cross-GPU sweep together (bounded in-kernel spins)
     for _ in range(args.warmup):
         one_iteration()
     sync_all()
