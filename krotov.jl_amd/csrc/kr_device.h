@@ -303,8 +303,11 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                                             double *spart /*[LMAX][ROWS]*/, double *stot /*[LMAX+1]*/) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, P = a.P;
+    // Tags count exchange events over the life of the handle (32-bit, wrapping); the buffer parity is taken from
+    // the TAG, not from the step index, so that consecutive events alternate buffers across launches as well:
+    // with peers on other GPUs nothing separates one launch's last step from the next launch's first one.
     const unsigned tag = a.epoch_base + (unsigned)n + 1u;
-    const int par = n & 1;
+    const int par = (int)(tag & 1u);
 
     // 1. the ROWS row owners of the workgroup deposit their partial sums
     if (writer) {

@@ -683,8 +683,9 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     a.X = h->X_d; a.alpha = h->S_d; a.eps_new = eps_new_dev; a.g_a_int = h->gint_d;
     a.dir = +1;
     a.epoch_base = h->epoch_base;
+    // next launch: first tag = last tag + 3 (odd step: buffer parity keeps alternating); 32-bit wrap-around is
+    // harmless because every slot is rewritten every second event and tags are only compared for equality
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
-    if (h->epoch_base > 0xfff00000u) h->epoch_base = 0;  // (tags restart; mailboxes hold older, larger tags only transiently)
     HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
     int rc = ev_mark(h, 2, false);
     if (rc) return rc;

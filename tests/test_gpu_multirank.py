@@ -18,6 +18,8 @@ def _problem(which):
     from krotov_jl_amd import workloads as wl
     if which == "rowsplit":   # N = 80 -> NP = 128, row-split kernels (several workgroups per trajectory)
         return wl.dense_problem(80, 8, 6, 1, 910, 0.05, 1.0), 6
+    if which == "odd_nt":     # odd N_T: consecutive launches must keep alternating the mailbox buffers
+        return wl.dense_problem(16, 61, 24, 2, 911, 0.1, 1.0), 24
     return wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0), 24
 
 
@@ -39,9 +41,10 @@ def _worker(rank, world, port, q, which="small"):
         eng.set_initial_states(p["psi0"][a:b])
         psiT = eng.forward(p["eps"])
         eps = p["eps"].copy()
-        for _ in range(2):
+        for it in range(4):
             _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"][a:b], K_global=K)
-            dist.barrier()
+            if it == 0:
+                dist.barrier()   # later iterations run unsynchronised: ranks may be a launch apart
             eps, ga, psiT = eng.iteration(eps, chiT, p["S"], p["lam"])
         q.put((rank, eps, ga, psiT))
         dist.barrier()
@@ -52,7 +55,7 @@ def _worker(rank, world, port, q, which="small"):
         raise
 
 
-@pytest.mark.parametrize("which", ["small", "rowsplit"])
+@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit"])
 def test_two_ranks_one_gpu_equals_unsharded(which):
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
@@ -81,7 +84,7 @@ def test_two_ranks_one_gpu_equals_unsharded(which):
         eng.set_initial_states(p["psi0"])
         psiT = eng.forward(p["eps"])
         eps = p["eps"].copy()
-        for _ in range(2):
+        for _ in range(4):
             _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
             eps, ga, psiT = eng.iteration(eps, chiT, p["S"], p["lam"])
     assert np.max(np.abs(got[0][0] - eps)) / np.max(np.abs(eps)) < 1e-12
