@@ -50,31 +50,34 @@ def cpu_baseline(p, log):
     import oracle_c as oc
     from krotov_jl_amd import workloads as wl
     N = p["H0"].shape[0]
-    Ks, NTs = (32, 64) if N >= 64 else (32, 500)
-    Ks = min(Ks, p["psi0"].shape[0])
-    NTs = min(NTs, len(p["tlist"]) - 1)
-    tl = p["tlist"][:NTs + 1]
-    eps, S = p["eps"][:, :NTs], p["S"][:, :NTs]
-    psi0, tgt = p["psi0"][:Ks], p["tgt"][:Ks]
+    K_all, NT_all = p["psi0"].shape[0], len(p["tlist"]) - 1
+    nth = oc.max_threads()
+    # (name, mode, threads, trajectories, intervals): the threaded variants get enough trajectories to occupy the cores
+    variants = [("reference_order_1thread", 0, 1, min(32, K_all), min(64 if N >= 64 else 500, NT_all)),
+                ("reference_order_allcores", 0, nth, min(max(32, nth), K_all), min(48 if N >= 64 else 500, NT_all)),
+                ("shared_propagator_allcores", 1, nth, min(max(32, nth), K_all), min(200 if N >= 64 else 500, NT_all))]
     out = {}
-    variants = [("reference_order_1thread", 0, 1), ("reference_order_allcores", 0, oc.max_threads()),
-                ("shared_propagator_allcores", 1, oc.max_threads())]
-    for name, mode, nth in variants:
+    for name, mode, nt_, Ks, NTs in variants:
+        tl = p["tlist"][:NTs + 1]
+        eps, S = p["eps"][:, :NTs], p["S"][:, :NTs]
+        psi0, tgt = p["psi0"][:Ks], p["tgt"][:Ks]
         t0 = time.perf_counter()
-        psiT, _ = oc.forward(p["H0"], p["Hc"], tl, eps, psi0, store=False, mode=mode, nthreads=nth)
+        psiT, _ = oc.forward(p["H0"], p["Hc"], tl, eps, psi0, store=False, mode=mode, nthreads=nt_)
         t_fw = time.perf_counter() - t0
         _, _, chiT = wl.chi_and_JT(p["functional"], psiT, tgt)
         t0 = time.perf_counter()
-        oc.iteration(p["H0"], p["Hc"], tl, eps, S, p["lam"], psi0, chiT, mode=mode, nthreads=nth)
+        oc.iteration(p["H0"], p["Hc"], tl, eps, S, p["lam"], psi0, chiT, mode=mode, nthreads=nt_)
         t_it = time.perf_counter() - t0
-        out[name] = {"value": 2.0 * Ks * NTs / t_it, "iter_s": t_it, "cores": nth}
+        out[name] = {"value": 2.0 * Ks * NTs / t_it, "iter_s": t_it, "cores": nt_, "K": Ks, "NT": NTs}
         log("cpu %s: %.3f s/iter on sample K=%d NT=%d (fw %.2fs)" % (name, t_it, Ks, NTs, t_fw))
+    Ks, NTs = out["reference_order_1thread"]["K"], out["reference_order_1thread"]["NT"]
     base = out["reference_order_1thread"]
     return {"value": base["value"], "unit": "state*timesteps/s", "cores": 1, "kind": "port",
             "sample": "same H0/Hc/pulses, K=%d of %d trajectories, first %d of %d intervals; one Krotov "
                       "iteration, dense Pade expm per trajectory per step (reference execution order)"
                       % (Ks, p["psi0"].shape[0], NTs, len(p["tlist"]) - 1),
-            "variants": {k: {"value": v["value"], "cores": v["cores"]} for k, v in out.items()}}
+            "variants": {k: {"value": v["value"], "cores": v["cores"], "sample_K": v["K"], "sample_NT": v["NT"]}
+                         for k, v in out.items()}}
 
 
 def main():
