@@ -390,3 +390,13 @@ def test_rowsplit_mailbox_tag_wrap(oracle_c):
         assert np.array_equal(again, first)
     psiT_o, _ = oracle_c.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False)
     assert np.max(np.abs(first - psiT_o)) < TOL_STATE
+
+
+@pytest.mark.parametrize("kt", ["1", "2", "4"])
+def test_trajectories_per_team_variants(oracle_c, monkeypatch, kt):
+    """Every KT instantiation (trajectories per team) at every padded size, forced through KROTOV_HIP_KT."""
+    monkeypatch.setenv("KROTOV_HIP_KT", kt)
+    for (N, NT, K, L, seed) in [(6, 8, 21, 1, 121), (13, 6, 11, 2, 122), (30, 5, 9, 1, 123), (50, 4, 7, 3, 124)]:
+        p = wl.dense_problem(N, NT, K, L, seed, 0.1, 2.0)
+        info = _run_case(oracle_c, p, check_storage=True)
+        assert info["KT"] == int(kt)
