@@ -9,7 +9,7 @@ from . import _capi
 from ._capi import KrotovHipError
 from .engine import HipEngine
 from . import workloads, distributed, optimize as _optimize_mod
-from .optimize import (ControlProblem, Trajectory, hamiltonian, optimize, optimize_krotov, KrotovResult, KrotovWrk,
+from .optimize import (ControlProblem, Trajectory, hamiltonian, liouvillian, optimize, optimize_krotov, KrotovResult, KrotovWrk,
                        J_T_sm, J_T_ss, J_T_re, make_chi, discretize, discretize_on_midpoints, flattop)
 
 __all__ = ["HipEngine", "KrotovHipError", "_capi"]

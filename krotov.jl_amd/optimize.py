@@ -24,7 +24,8 @@ import numpy as np
 from .workloads import flattop  # noqa: F401  (re-exported for problem set-up)
 
 __all__ = [
-    "Trajectory", "ControlProblem", "Generator", "hamiltonian", "liouvillian_generator", "optimize", "optimize_krotov",
+    "Trajectory", "ControlProblem", "Generator", "hamiltonian", "liouvillian", "liouvillian_generator", "optimize",
+    "optimize_krotov",
     "KrotovResult", "KrotovWrk", "J_T_sm", "J_T_ss", "J_T_re", "make_chi", "discretize",
     "discretize_on_midpoints", "get_controls", "make_krotov_print_iters",
 ]
@@ -89,6 +90,27 @@ def hamiltonian(H0, *terms):
 
 
 liouvillian_generator = hamiltonian  # a Liouvillian in the d rho/dt = -i L rho convention is used the same way
+
+
+def liouvillian(H, c_ops=(), convention="TDSE"):
+    """QuantumPropagators.liouvillian(H, c_ops; convention=:TDSE) [UPSTREAM-RECALLED] for dense operators: the
+    generator of d vec(rho)/dt = -i L vec(rho) (row-major vec: vec(A rho B) = (A kron B^T) vec(rho)), with
+    L = [H, .] + i sum_j D[c_j], D[c] rho = c rho c^+ - {c^+ c, rho}/2.  `H` may be a matrix or a Generator with
+    control terms; every control term H_l becomes [H_l, .] with the same control.  States are vec(rho)."""
+    if convention != "TDSE":
+        raise ValueError("only convention='TDSE' (d rho/dt = -i L rho) is supported")
+    gen = H if isinstance(H, Generator) else Generator(H, [])
+    n = gen.H0.shape[0]
+    I = np.eye(n)
+
+    def comm(A):
+        return np.kron(A, I) - np.kron(I, A.T)
+    L0 = comm(gen.H0).astype(np.complex128)
+    for c in c_ops:
+        c = np.asarray(c, np.complex128)
+        cdc = c.conj().T @ c
+        L0 = L0 + 1j * (np.kron(c, c.conj()) - 0.5 * np.kron(cdc, I) - 0.5 * np.kron(I, cdc.T))
+    return Generator(L0, [(comm(op), ctrl) for op, ctrl in zip(gen.ops, gen.controls)])
 
 
 class Trajectory:
@@ -330,6 +352,28 @@ def _convert_result(other, problem):
     return r
 
 
+class _PropView:
+    """What a per-step propagation callback gets to see (optimize.jl:258-262, 310-314, 362-366): the propagator's
+    `state`, the time-grid index and the trajectory index.  The sweeps run on the device as a whole, so the
+    callbacks are REPLAYED from the device storages right after each sweep, in the reference's order (for k, for n)."""
+
+    def __init__(self, state, tlist, i, k, backward):
+        self.state, self.tlist, self.i, self.k, self.backward = state, tlist, i, k, backward
+        self.t = tlist[i]
+
+
+def _replay_prop_callbacks(wrk, which):
+    key = {"fw": ("fw_prop_callback", "prop_callback"), "bw": ("bw_prop_callback", "prop_callback")}[which]
+    cb = next((wrk.kwargs[k] for k in key if k in wrk.kwargs), None)
+    if cb is None or not hasattr(wrk.engine, "read_storage"):
+        return
+    NT = len(wrk.result.tlist) - 1
+    steps = range(1, NT + 1) if which == "fw" else range(NT - 1, -1, -1)
+    for k in range(len(wrk.trajectories)):
+        for n in steps:
+            cb(_PropView(wrk.engine.read_storage(which, k, n), wrk.result.tlist, n, k, which == "bw"), None)
+
+
 # ------------------------------------------------------------------ driver (optimize.jl:161-235)
 def _update_result(wrk, i):
     """update_result! (optimize.jl:374-397)."""
@@ -370,6 +414,8 @@ def _krotov_iteration(wrk, eps_i, eps_ip1):
     S = np.array(wrk.update_shapes)
     lam = np.array(wrk.lambda_vals)
     eps_new, g_a_int, psiT = wrk.engine.iteration(np.array(eps_i), np.array(chiT), S, lam)
+    _replay_prop_callbacks(wrk, "bw")
+    _replay_prop_callbacks(wrk, "fw")
     for l in range(len(eps_ip1)):
         eps_ip1[l][:] = eps_new[l]  # in-place: callbacks hold references to these vectors
     wrk.g_a_int[:] = g_a_int
@@ -392,6 +438,7 @@ def optimize_krotov(problem):
         wrk.final_states = [t.initial_state.copy() for t in wrk.trajectories]
     else:
         psiT = wrk.engine.forward(np.array(eps_i))  # krotov_initial_fw_prop! for all k (optimize.jl:182-184)
+        _replay_prop_callbacks(wrk, "fw")
         wrk.final_states = [psiT[k] for k in range(psiT.shape[0])]
     _update_result(wrk, 0)
     info = callback(wrk, 0, eps_ip1, eps_i)

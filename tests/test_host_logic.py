@@ -167,3 +167,39 @@ def test_ensemble_of_generators_through_driver():
     res = kr.optimize(problem, store_iter_info=["J_T"], print_iters_out=out)
     J = [r[0] for r in res.records]
     assert J[3] < J[2] < J[1] < J[0]
+
+
+def test_liouvillian_helper_matches_master_equation():
+    """liouvillian(H, c_ops): d vec(rho)/dt = -i L vec(rho) must reproduce -i[H,rho] + D[c]rho."""
+    rng = np.random.default_rng(5)
+    n = 3
+    A = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    H0 = (A + A.conj().T) / 2
+    c = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    B = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    rho = B @ B.conj().T
+    rho /= np.trace(rho)
+    L = kr.liouvillian(kr.hamiltonian(H0), [c])
+    lhs = (-1j * L.H0 @ rho.reshape(-1)).reshape(n, n)
+    cdc = c.conj().T @ c
+    rhs = -1j * (H0 @ rho - rho @ H0) + c @ rho @ c.conj().T - 0.5 * (cdc @ rho + rho @ cdc)
+    assert np.max(np.abs(lhs - rhs)) < 1e-13
+    ctrl = lambda t: 0.1
+    L2 = kr.liouvillian(kr.hamiltonian(H0, (A + A.conj().T, ctrl)), [c])
+    assert len(L2.ops) == 1 and L2.controls[0] is ctrl and L2.H0.shape == (9, 9)
+
+
+def test_prop_callbacks_are_replayed():
+    """fw/bw per-step callbacks (optimize.jl:258-262, 310-314): replayed from the storages after each sweep."""
+    seen = {"fw": 0, "bw": 0}
+
+    def fw_cb(prop, observables):
+        assert not prop.backward and prop.state.shape == (2,)
+        seen["fw"] += 1
+
+    def bw_cb(prop, observables):
+        assert prop.backward
+        seen["bw"] += 1
+    problem = tls_problem(iter_stop=1, J_T=kr.J_T_sm, fw_prop_callback=fw_cb, bw_prop_callback=bw_cb, keep_engine=True)
+    kr.optimize(problem, print_iters=False)
+    assert seen["fw"] == 2 * 500 and seen["bw"] == 500   # initial sweep + iteration 1; one backward sweep
