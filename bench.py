@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traj", type=int, default=0, help="(testing) override the trajectories per GPU of the config")
     return ap.parse_args()
 
 
@@ -102,14 +103,24 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # KROTOV_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
+    backend = os.environ.get("KROTOV_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    red_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     p = wl.config(args.config)
+    if args.traj > 0:
+        p["psi0"], p["tgt"] = p["psi0"][:args.traj], p["tgt"][:args.traj]
     K_local, N = p["psi0"].shape
     L, NT = p["eps"].shape
     K_global = K_local * world
@@ -132,7 +143,7 @@ def main():
         except Exception as exc:  # noqa: BLE001
             log("rank %d: peer mailbox set-up failed: %r" % (rank, exc))
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", local_rank))
+        flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             if eng is not None:
@@ -180,7 +191,7 @@ def main():
     tm = eng.timings_ms()
     eng.enable_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     J1 = wl.chi_and_JT(p["functional"], eng.final_states(), p["tgt"], K_global)[1]

@@ -38,3 +38,20 @@ def test_bench_json_contract():
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
     assert d["value"] > 0 and d["J_T"]["after"] < d["J_T"]["before"]
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N > 1 path (torch.distributed launch, IPC mailbox wiring, max-over-ranks timing) with two ranks
+    sharing the one GPU (gloo instead of RCCL, fewer trajectories so that both persistent kernels are resident)."""
+    env = dict(os.environ, KROTOV_BENCH_BACKEND="gloo", KROTOV_HIP_MAX_WG="100")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--traj", "64",
+                          "--config", "C2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "sharded over 2" in d["config"]["parallelism"]
