@@ -297,6 +297,39 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #define KR_POLL_SLEEP 0  // measured at P = 256: 0 -> 7.48 ms per update sweep, 1 -> 7.55, 4 -> 7.60, 16 -> 7.78
 #endif
 #define KR_POLL_CHUNKS 4  // slots per lane gathered with all loads in flight at once (P <= 256 in one go)
+// One poll pass with 16-byte loads: lane reads up to KR_POLL_CHUNKS slots (slot = LMAX 16-byte words {lo32, tag, hi32,
+// tag}, i.e. two self-validating 8-byte granules per word, so tearing between the halves of a word is harmless) with loads
+// that bypass the vector L1 (sc1).  All loads of a pass and their wait are ONE asm block: the compiler does not count asm
+// loads in vmcnt, so nothing may touch the results before the block ends.  Used by the row-split all-gather
+// (kr_device_rowsplit.h; C5 known-pulse sweeps 37.9 -> 34.3 us per step).  In isolation (tools/ubench/exchange.hip,
+// P = 256) this form also makes the per-step exchange faster (8-byte loads 2.70 us, 16-byte buffer loads emitted by the
+// compiler 2.29, this form 1.55-1.96; floor = one store->load round trip through memory, 1.35), but inside
+// kr_sweep_update it does not (same-box A/B at C3: 7.15-7.19 against 7.19-7.28 us per step; C2, P = 8: 4.14 against
+// 4.45): there the exchange is bound by the time the 256 partial stores take to become visible (first pass, which also
+// waits for the publishing store's acknowledgement, 1.2-1.9 us; later passes 0.75 us), so kr_exchange keeps its 8-byte
+// loads.  What does help there is an uncached (MTYPE UC) mailbox allocation: see alloc_mailbox in krotov_hip.hip.
+typedef unsigned int kr_v4u __attribute__((ext_vector_type(4)));
+#define KR_PL(o, p, off) "global_load_dwordx4 %" #o ", %" #p ", off offset:" #off " sc1\n\t"
+template <int LMAX> struct KrPoll;
+template <> struct KrPoll<2> {
+    static __device__ __forceinline__ void pass(const unsigned long long *p0, const unsigned long long *p1,
+                                                const unsigned long long *p2, const unsigned long long *p3, const int nch,
+                                                kr_v4u (&g)[KR_POLL_CHUNKS][2]) {
+        if (nch > 2) {
+            asm volatile(KR_PL(0, 8, 0) KR_PL(1, 8, 16) KR_PL(2, 9, 0) KR_PL(3, 9, 16) KR_PL(4, 10, 0) KR_PL(5, 10, 16)
+                         KR_PL(6, 11, 0) KR_PL(7, 11, 16) "s_waitcnt vmcnt(0)"
+                         : "=&v"(g[0][0]), "=&v"(g[0][1]), "=&v"(g[1][0]), "=&v"(g[1][1]), "=&v"(g[2][0]), "=&v"(g[2][1]),
+                           "=&v"(g[3][0]), "=&v"(g[3][1])
+                         : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+        } else if (nch > 1) {
+            asm volatile(KR_PL(0, 4, 0) KR_PL(1, 4, 16) KR_PL(2, 5, 0) KR_PL(3, 5, 16) "s_waitcnt vmcnt(0)"
+                         : "=&v"(g[0][0]), "=&v"(g[0][1]), "=&v"(g[1][0]), "=&v"(g[1][1]) : "v"(p0), "v"(p1) : "memory");
+        } else {
+            asm volatile(KR_PL(0, 2, 0) KR_PL(1, 2, 16) "s_waitcnt vmcnt(0)" : "=&v"(g[0][0]), "=&v"(g[0][1]) : "v"(p0) : "memory");
+        }
+    }
+};
+
 template <int LMAX, int ROWS>
 __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg, const bool writer,
                                             const int rowid, const double (&part)[LMAX], double (&total)[LMAX],

@@ -66,43 +66,41 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
     const int par = box.counter & 1;
     kr_gu64 *mb = (kr_gu64 *)(box.base + (size_t)par * NP * 4);
     if (owner) {
+        // one 16-byte store per component: {lo32, tag, hi32, tag} = two self-validating granules
         const int e = rb * NR + il;
         const unsigned long long br = (unsigned long long)__double_as_longlong(vr), bi = (unsigned long long)__double_as_longlong(vi);
-        const unsigned long long t = (unsigned long long)tag << 32;
-        __hip_atomic_store(mb + 4 * e + 0, t | (br & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mb + 4 * e + 1, t | (br >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mb + 4 * e + 2, t | (bi & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mb + 4 * e + 3, t | (bi >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        kr_v4u wr, wi;
+        wr.x = (unsigned)br; wr.y = tag; wr.z = (unsigned)(br >> 32); wr.w = tag;
+        wi.x = (unsigned)bi; wi.y = tag; wi.z = (unsigned)(bi >> 32); wi.w = tag;
+        const unsigned long long *pe = (const unsigned long long *)mb + 4 * e;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(pe), "v"(wr), "v"(wi) : "memory");
         dst[e + e / JS] = make_double2(vr, vi);  // own block goes straight to LDS
     }
     // wave 0 gathers the NP - NR foreign elements: lane handles elements lane, lane + 64, ...; every load of a pass
-    // is in flight before the first tag is looked at (no workgroup barrier inside the spin)
+    // is in flight before the first tag is looked at (no workgroup barrier inside the spin); 16-byte sc1 loads, the
+    // loads of a pass and their wait in one asm block (KrPoll, kr_device.h)
     bool alive = true;
     if ((tid >> 6) == 0) {
         constexpr int EC = (NP - NR + 63) / 64;
+        static_assert(EC <= KR_POLL_CHUNKS, "at most 256 foreign elements");
         const int lane = tid & 63;
-        int el[EC];
+        int el[KR_POLL_CHUNKS];
 #pragma unroll
-        for (int c = 0; c < EC; ++c) {
+        for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
             int q = min(lane + 64 * c, NP - NR - 1);
             if (q >= rb * NR) q += NR;
             el[c] = q;
         }
-        unsigned long long g[EC][4];
+        const unsigned long long *mbc = (const unsigned long long *)mb;
+        kr_v4u g[KR_POLL_CHUNKS][2];
         const unsigned long long t0 = kr_realtime();
         unsigned spins = 0;
         for (;;) {
             bool ok = true;
+            KrPoll<2>::pass(mbc + 4 * el[0], mbc + 4 * el[1], mbc + 4 * el[2], mbc + 4 * el[3], EC, g);
 #pragma unroll
-            for (int c = 0; c < EC; ++c) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) g[c][w] = __hip_atomic_load(mb + 4 * el[c] + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int c = 0; c < EC; ++c) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) ok = ok & ((unsigned)(g[c][w] >> 32) == tag);
-            }
+            for (int c = 0; c < EC; ++c)
+                ok = ok & (g[c][0].y == tag) & (g[c][0].w == tag) & (g[c][1].y == tag) & (g[c][1].w == tag);
             if (__all(ok)) break;
             if ((++spins & 63u) == 0u) {
                 const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -121,8 +119,8 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
                 if (lane + 64 * c < NP - NR) {
-                    const double re = __longlong_as_double((long long)((g[c][1] << 32) | (g[c][0] & 0xffffffffull)));
-                    const double im = __longlong_as_double((long long)((g[c][3] << 32) | (g[c][2] & 0xffffffffull)));
+                    const double re = __longlong_as_double((long long)(((unsigned long long)g[c][0].z << 32) | g[c][0].x));
+                    const double im = __longlong_as_double((long long)(((unsigned long long)g[c][1].z << 32) | g[c][1].x));
                     dst[el[c] + el[c] / JS] = make_double2(re, im);
                 }
             }

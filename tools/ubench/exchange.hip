@@ -1,0 +1,302 @@
+// Micro-benchmark of the per-step exchange of the update sweep in isolation: P persistent workgroups, every
+// iteration each publishes LQ granules {tag32 | half of a double} and obtains the sum over all workgroups.
+//   variant 0: flat all-to-all (what kr_exchange does): every workgroup polls all P slots, agent scope
+//   variant 1: two levels: workgroups with equal blockIdx % 8 (one XCD under round-robin placement, checked here
+//              through HW_REG_XCC_ID) gather through their XCD's L2 (sc0 = "workgroup"-scope accesses: bypass the
+//              vector L1, hit the L2), member 0 publishes the XCD total at agent scope, everyone polls the 8 totals
+//   variant 2: as 1 but the first level at agent scope too (isolates "fewer lines per poll" from "L2 hit")
+//   variant 3: as 1 with sc0 stores (line stays in the XCD's L2) and sc1 loads (bypass L1, L2-served) at the first level
+// `work` = s_sleep units of fake compute between exchanges (one unit = 64 cycles).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef unsigned long long u64;
+#define LQ 4  // granules per slot (L = 2 doubles)
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int SCOPE>
+__device__ __forceinline__ void gstore(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, SCOPE); }
+template <int SCOPE>
+__device__ __forceinline__ u64 gload(u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, SCOPE); }
+
+// gather `cnt` slots (<= 256) of LQ granules starting at base; returns per-l sums (lane-reduced) in tot[2]
+template <int SCOPE>
+__device__ __forceinline__ bool gather(u64 *base, int cnt, unsigned tag, double (&tot)[2], int lane) {
+    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+        bool ok = true;
+        tot[0] = tot[1] = 0.0;
+        u64 g[4][LQ];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (64 * c < cnt) {
+                const int q = min(64 * c + lane, cnt - 1);
+#pragma unroll
+                for (int w = 0; w < LQ; ++w) g[c][w] = gload<SCOPE>(base + (size_t)q * LQ + w);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (64 * c < cnt) {
+                const bool mine = (64 * c + lane) < cnt;
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    const u64 g0 = g[c][2 * l], g1 = g[c][2 * l + 1];
+                    const bool good = ((unsigned)(g0 >> 32) == tag) & ((unsigned)(g1 >> 32) == tag);
+                    ok = ok & (good | !mine);
+                    const u64 bits = (g1 << 32) | (g0 & 0xffffffffull);
+                    tot[l] += mine ? __longlong_as_double((long long)bits) : 0.0;
+                }
+            }
+        }
+        if (__all(ok)) { tot[0] = wave_sum(tot[0]); tot[1] = wave_sum(tot[1]); return true; }
+    }
+    return false;
+}
+
+// ---- 16-B sc1 buffer loads (each 8-B granule validates itself, so tearing between the halves is harmless) ----
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#define AUX_SC1 16
+template <int NCH>
+__device__ __forceinline__ void issue16(__amdgpu_buffer_rsrc_t r, int base, int first, int cnt, int lane, u4 (&g)[NCH][2]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (64 * c < cnt) {
+            const int q = first + min(64 * c + lane, cnt - 1);
+            g[c][0] = __builtin_amdgcn_raw_buffer_load_b128(r, base + q * 32, 0, AUX_SC1);
+            g[c][1] = __builtin_amdgcn_raw_buffer_load_b128(r, base + q * 32 + 16, 0, AUX_SC1);
+        }
+    }
+}
+template <int NCH>
+__device__ __forceinline__ bool check16(const u4 (&g)[NCH][2], int cnt, unsigned tag, int lane, double (&tot)[2]) {
+    bool ok = true;
+    tot[0] = tot[1] = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (64 * c < cnt) {
+            const bool mine = (64 * c + lane) < cnt;
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const bool good = (g[c][l].y == tag) & (g[c][l].w == tag);
+                ok = ok & (good | !mine);
+                const u64 bits = ((u64)g[c][l].z << 32) | g[c][l].x;
+                tot[l] += mine ? __longlong_as_double((long long)bits) : 0.0;
+            }
+        }
+    }
+    return __all(ok);
+}
+// variant 7: global_load_dwordx4 sc1 through inline asm; the loads of a pass and their wait form ONE asm block, so the
+// compiler (which does not count asm loads in vmcnt) can never touch the results early
+// slot -> offset in u64 units; SPREAD: 32 slots (1 KB) per 8 KB + 1 KB block, so that the 8 blocks fall into different channels
+template <int SPREAD>
+__device__ __forceinline__ size_t slot_off(int q) { return SPREAD ? (size_t)(q >> 5) * (9216 / 8) + (size_t)(q & 31) * 4 : (size_t)q * 4; }
+template <int SPREAD = 0>
+__device__ __forceinline__ void issue16_asm(const u64 *mail, int first, int cnt, int lane, u4 (&g)[4][2]) {
+    const u64 *p0 = mail + slot_off<SPREAD>(first + min(lane, cnt - 1));
+    const u64 *p1 = mail + slot_off<SPREAD>(first + min(64 + lane, cnt - 1));
+    const u64 *p2 = mail + slot_off<SPREAD>(first + min(128 + lane, cnt - 1));
+    const u64 *p3 = mail + slot_off<SPREAD>(first + min(192 + lane, cnt - 1));
+    if (cnt > 128) {
+        asm volatile("global_load_dwordx4 %0, %8, off sc1\n global_load_dwordx4 %1, %8, off offset:16 sc1\n"
+                     "global_load_dwordx4 %2, %9, off sc1\n global_load_dwordx4 %3, %9, off offset:16 sc1\n"
+                     "global_load_dwordx4 %4, %10, off sc1\n global_load_dwordx4 %5, %10, off offset:16 sc1\n"
+                     "global_load_dwordx4 %6, %11, off sc1\n global_load_dwordx4 %7, %11, off offset:16 sc1\n"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(g[0][0]), "=&v"(g[0][1]), "=&v"(g[1][0]), "=&v"(g[1][1]), "=&v"(g[2][0]), "=&v"(g[2][1]), "=&v"(g[3][0]), "=&v"(g[3][1])
+                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+    } else if (cnt > 64) {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n global_load_dwordx4 %1, %4, off offset:16 sc1\n"
+                     "global_load_dwordx4 %2, %5, off sc1\n global_load_dwordx4 %3, %5, off offset:16 sc1\n"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(g[0][0]), "=&v"(g[0][1]), "=&v"(g[1][0]), "=&v"(g[1][1]) : "v"(p0), "v"(p1) : "memory");
+    } else {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n global_load_dwordx4 %1, %2, off offset:16 sc1\n"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(g[0][0]), "=&v"(g[0][1]) : "v"(p0) : "memory");
+    }
+}
+template <int SPREAD = 0>
+__device__ __forceinline__ bool gather16_asm(const u64 *mail, int cnt, unsigned tag, double (&tot)[2], int lane) {
+    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+        u4 g[4][2];
+        issue16_asm<SPREAD>(mail, 0, cnt, lane, g);
+        if (check16<4>(g, cnt, tag, lane, tot)) { tot[0] = wave_sum(tot[0]); tot[1] = wave_sum(tot[1]); return true; }
+    }
+    return false;
+}
+
+template <int NCH, int DEPTH>
+__device__ __forceinline__ bool gather16(__amdgpu_buffer_rsrc_t r, int base, int first, int cnt, unsigned tag, double (&tot)[2], int lane) {
+    u4 cur[NCH][2];
+    issue16<NCH>(r, base, first, cnt, lane, cur);
+    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+        if (DEPTH == 2) {
+            u4 nxt[NCH][2];
+            issue16<NCH>(r, base, first, cnt, lane, nxt);
+            if (check16<NCH>(cur, cnt, tag, lane, tot)) { tot[0] = wave_sum(tot[0]); tot[1] = wave_sum(tot[1]); return true; }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { cur[c][0] = nxt[c][0]; cur[c][1] = nxt[c][1]; }
+        } else {
+            if (check16<NCH>(cur, cnt, tag, lane, tot)) { tot[0] = wave_sum(tot[0]); tot[1] = wave_sum(tot[1]); return true; }
+            issue16<NCH>(r, base, first, cnt, lane, cur);
+        }
+    }
+    return false;
+}
+
+template <int SCOPE>
+__device__ __forceinline__ void publish(u64 *slot, unsigned tag, double v0, double v1, int lane) {
+    if (lane < LQ) {
+        const double v = (lane >> 1) ? v1 : v0;
+        const u64 bits = (u64)__double_as_longlong(v);
+        const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        gstore<SCOPE>(slot + lane, ((u64)tag << 32) | half);
+    }
+}
+
+// variants 4 (16-B buffer loads), 5 (same, two passes in flight), 6 (four waves poll 64 slots each), 7 (16-B global loads)
+__global__ __launch_bounds__(256) void exch16(int variant, u64 *mail, double *out, u64 *cyc, int P, int iters, int work, unsigned *fail) {
+    __shared__ double sp[2][4][2];
+    __shared__ int sfail;
+    const int wg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)mail, 0, 2 * 256 * 32, 0x00020000);
+    double acc0 = 0, acc1 = 0;
+    u64 t0 = 0;
+    if (threadIdx.x == 0) sfail = 0;
+    __syncthreads();
+    for (int n = 0; n < iters + 8; ++n) {
+        if (n == 8) t0 = wall_clock64();
+        const unsigned tag = (unsigned)n + 1u;
+        const int par = tag & 1;
+        const double v0 = 1.0 + wg * 1e-3 + n * 1e-6, v1 = -0.5 * v0;
+        double tot[2];
+        bool ok = true;
+        if (variant == 9) {  // slots spread over 8 blocks 9 KB apart
+            if (wave == 0) publish<__HIP_MEMORY_SCOPE_AGENT>(mail + (size_t)par * 10240 + slot_off<1>(wg), tag, v0, v1, lane);
+        } else if (variant == 10) {  // one replica of the mailbox per XCD group (blockIdx % 8), replicas 9 KB apart
+            if (wave == 0 && lane < 32) {
+                const int rep = lane >> 2, gq = lane & 3;
+                const double v = (gq >> 1) ? v1 : v0;
+                const u64 bits = (u64)__double_as_longlong(v);
+                const unsigned half = (gq & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+                gstore<__HIP_MEMORY_SCOPE_AGENT>(mail + (size_t)par * 10240 + (size_t)rep * (9216 / 8) + (size_t)wg * 4 + gq, ((u64)tag << 32) | half);
+            }
+        } else
+        if (variant == 8) {  // one 16-B sc1 store per double: {lo, tag, hi, tag}
+            if (wave == 0 && lane < 2) {
+                const u64 bits = (u64)__double_as_longlong(lane ? v1 : v0);
+                u4 q; q.x = (unsigned)bits; q.y = tag; q.z = (unsigned)(bits >> 32); q.w = tag;
+                const u64 *dst = mail + ((size_t)par * P + wg) * LQ + 2 * lane;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(q) : "memory");
+            }
+        } else
+        if (wave == 0) publish<__HIP_MEMORY_SCOPE_AGENT>(mail + ((size_t)par * P + wg) * LQ, tag, v0, v1, lane);
+        if (variant == 9) {
+            if (wave == 0) ok = gather16_asm<1>(mail + (size_t)par * 10240, P, tag, tot, lane);
+        } else if (variant == 10) {
+            if (wave == 0) ok = gather16_asm<0>(mail + (size_t)par * 10240 + (size_t)(wg & 7) * (9216 / 8), P, tag, tot, lane);
+        } else if (variant >= 7) {
+            if (wave == 0) ok = gather16_asm(mail + (size_t)par * P * LQ, P, tag, tot, lane);
+        } else if (variant == 6) {
+            const int first = wave * 64, cnt = min(64, P - first);
+            if (cnt > 0) {
+                ok = gather16_asm<0>(mail + (size_t)par * P * LQ + (size_t)first * 4, cnt, tag, tot, lane);
+                if (lane == 0) { sp[par][wave][0] = tot[0]; sp[par][wave][1] = tot[1]; if (!ok) sfail = 1; }
+            }
+            __syncthreads();
+            tot[0] = tot[1] = 0.0;
+            for (int w = 0; w * 64 < P; ++w) { tot[0] += sp[par][w][0]; tot[1] += sp[par][w][1]; }
+            ok = !sfail;
+        } else if (wave == 0) {
+            ok = (variant == 4) ? gather16<4, 1>(r, par * P * 32, 0, P, tag, tot, lane) : gather16<4, 2>(r, par * P * 32, 0, P, tag, tot, lane);
+        }
+        if (variant != 6 && wave != 0) { tot[0] = tot[1] = 0; }
+        if (!ok) { if (threadIdx.x == 0) atomicAdd(fail, 1u); break; }
+        acc0 += tot[0]; acc1 += tot[1];
+        for (int w = 0; w < work; ++w) __builtin_amdgcn_s_sleep(1);
+    }
+    const u64 t1 = wall_clock64();
+    if (threadIdx.x == 0) { out[2 * wg] = acc0; out[2 * wg + 1] = acc1; cyc[wg] = t1 - t0; }
+}
+
+__global__ __launch_bounds__(64) void exch(int variant, u64 *mail, u64 *mailB, double *out, u64 *cyc, unsigned *xcc,
+                                            int P, int iters, int work, unsigned *fail) {
+    const int wg = blockIdx.x, lane = threadIdx.x;
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    if (lane == 0) xcc[wg] = id;
+    const int grp = wg & 7, idx = wg >> 3, G = (P + 7 - grp) / 8;
+    double acc0 = 0, acc1 = 0;
+    u64 t0 = 0;
+    for (int n = 0; n < iters + 8; ++n) {
+        if (n == 8) t0 = wall_clock64();
+        const unsigned tag = (unsigned)n + 1u;
+        const int par = tag & 1;
+        const double v0 = 1.0 + wg * 1e-3 + n * 1e-6, v1 = -0.5 * v0;
+        double tot[2];
+        bool ok = true;
+        if (variant == 0) {
+            publish<__HIP_MEMORY_SCOPE_AGENT>(mail + ((size_t)par * P + wg) * LQ, tag, v0, v1, lane);
+            ok = gather<__HIP_MEMORY_SCOPE_AGENT>(mail + (size_t)par * P * LQ, P, tag, tot, lane);
+        } else {
+            u64 *gbase = mail + ((size_t)par * 8 + grp) * 64 * LQ;  // up to 64 members per group, 2 KB apart
+            if (variant == 1) {
+                publish<__HIP_MEMORY_SCOPE_WORKGROUP>(gbase + (size_t)idx * LQ, tag, v0, v1, lane);
+                ok = gather<__HIP_MEMORY_SCOPE_WORKGROUP>(gbase, G, tag, tot, lane);
+            } else if (variant == 2) {
+                publish<__HIP_MEMORY_SCOPE_AGENT>(gbase + (size_t)idx * LQ, tag, v0, v1, lane);
+                ok = gather<__HIP_MEMORY_SCOPE_AGENT>(gbase, G, tag, tot, lane);
+            } else {
+                publish<__HIP_MEMORY_SCOPE_WORKGROUP>(gbase + (size_t)idx * LQ, tag, v0, v1, lane);
+                ok = gather<__HIP_MEMORY_SCOPE_AGENT>(gbase, G, tag, tot, lane);
+            }
+            if (ok) {
+                if (idx == 0) publish<__HIP_MEMORY_SCOPE_AGENT>(mailB + ((size_t)par * 8 + grp) * LQ, tag, tot[0], tot[1], lane);
+                ok = gather<__HIP_MEMORY_SCOPE_AGENT>(mailB + (size_t)par * 8 * LQ, min(P, 8), tag, tot, lane);
+            }
+        }
+        if (!ok) { if (lane == 0) atomicAdd(fail, 1u); break; }
+        acc0 += tot[0]; acc1 += tot[1];
+        for (int w = 0; w < work; ++w) __builtin_amdgcn_s_sleep(1);
+    }
+    const u64 t1 = wall_clock64();
+    if (lane == 0) { out[2 * wg] = acc0; out[2 * wg + 1] = acc1; cyc[wg] = t1 - t0; }
+}
+
+int main(int argc, char **argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+    u64 *mail, *mailB, *cyc; double *out; unsigned *xcc, *fail;
+    hipMalloc(&mail, 2 * 10240 * 8);
+    hipMalloc(&mailB, 2 * 8 * LQ * 8);
+    hipMalloc(&out, 256 * 2 * 8); hipMalloc(&cyc, 256 * 8); hipMalloc(&xcc, 256 * 4); hipMalloc(&fail, 4);
+    for (int P : {8, 64, 256}) {
+        for (int work : {0, 64}) {
+            for (int variant = 0; variant < 11; ++variant) {
+                if (variant == 1 && P > 8) continue;  // sc0 loads hit the (stale) L1: never completes
+                hipMemset(mail, 0, 2 * 10240 * 8); hipMemset(mailB, 0, 2 * 8 * LQ * 8);
+                hipMemset(fail, 0, 4);
+                if (variant >= 4) hipLaunchKernelGGL(exch16, dim3(P), dim3(variant == 6 ? 256 : 64), 0, 0, variant, mail, out, cyc, P, iters, work, fail);
+                else hipLaunchKernelGGL(exch, dim3(P), dim3(64), 0, 0, variant, mail, mailB, out, cyc, xcc, P, iters, work, fail);
+                if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
+                std::vector<u64> c(P); std::vector<double> o(2 * P); std::vector<unsigned> x(P); unsigned f;
+                hipMemcpy(c.data(), cyc, P * 8, hipMemcpyDeviceToHost); hipMemcpy(o.data(), out, 2 * P * 8, hipMemcpyDeviceToHost);
+                hipMemcpy(x.data(), xcc, P * 4, hipMemcpyDeviceToHost); hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost);
+                bool same = true, rr = true;
+                for (int w = 1; w < P; ++w) same = same && o[2 * w] == o[0] && o[2 * w + 1] == o[1];
+                for (int w = 8; w < P; ++w) rr = rr && ((x[w] & 15) == (x[w - 8] & 15));
+                // wall_clock64: 100 MHz
+                printf("P=%3d work=%2d variant=%d: %.3f us/exchange  (sum %.6f, all equal %d, fails %u, wg%%8 shares XCC %d, xcc[0..7]=%u %u %u %u %u %u %u %u)\n",
+                       P, work, variant, (double)c[0] / iters * 0.01, o[0], (int)same, f, (int)rr,
+                       x[0] & 15, x[1 % P] & 15, x[2 % P] & 15, x[3 % P] & 15, x[4 % P] & 15, x[5 % P] & 15, x[6 % P] & 15, x[7 % P] & 15);
+            }
+        }
+    }
+    return 0;
+}
