@@ -32,6 +32,7 @@ struct KrSweepArgs {
     const double *alpha;     // [L][NT] = S[l][n] / lambda[l] (optimize.jl:354), divided once on the host
     double *eps_new;         // [L][NT]
     double *g_a_int;         // [L]
+    int poll_delay;            // exchange schedule 1 (kr_exchange): wave 0 starts polling after poll_delay x 128 cycles
     unsigned long long *mail;  // [2][P][2*LMAX] granules {tag32 | half of a double}
     unsigned long long *xmail; // [2][world][2*LMAX] inter-GPU granules (local memory, peers write)
     unsigned long long *peer_xmail[8]; // every rank's xmail (peer_xmail[rank] == xmail)
@@ -116,7 +117,8 @@ __device__ __forceinline__ void kr_plan_fast(const KrSweepArgs &a, const double 
 typedef hipError_t (*kr_launch_fn)(int variant_lmax, int variant_kt, int kind, int grid,
                                    hipStream_t stream, const KrSweepArgs *args);
 // kind: 0 = known-pulse sweep (Taylor), 1 = update sweep, 2 = batched propagator build (grid = NT),
-//       3 = known-pulse sweep with precomputed propagators
+//       3 = known-pulse sweep with precomputed propagators, 4 = update sweep with the delayed-poll exchange schedule
+//       (N <= 64 only)
 hipError_t kr_launch_np8(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np16(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np32(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);

@@ -283,8 +283,15 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 // total.  Slots are double-buffered by step parity; tags increase monotonically over the life of
 // the handle, so nothing needs clearing between launches.  Spins are bounded.
 // Wave 0 issues NO other vector-memory operation in the update kernel (state loads/stores belong
-// to the last wave): vmcnt retires in order, so an HBM load or a store acknowledgement queued in
-// front of the poll would otherwise sit on the critical path of every step.
+// to the last wave): vmcnt retires in order and counts loads and stores together, so an HBM load or
+// a store acknowledgement queued in front of the poll sits on the critical path of every step.
+// Two schedules (template parameter SCHED; chosen per handle by calibrate_exchange in krotov_hip.hip):
+//   0    wave 0 publishes, then polls: its first pass also waits for the store's acknowledgement
+//        (1.2-1.9 us at P = 256), the second one (0.75 us) finds all tags;
+//   1    wave 1 publishes (asm store, never waited for), wave 0 sleeps a.poll_delay x 128 cycles and
+//        then polls: with the right delay its FIRST pass finds all tags (C3: 7.0 -> 6.65 us/step);
+//        polling at once instead is slower than the first schedule (the stores become visible later
+//        under 256 polling workgroups).
 // Returns false when the exchange was aborted (status[0] set).
 // =============================================================================================
 // Mailbox slot = 2*LMAX granules, packed (32 B for LMAX = 2).  Measured at P = 256 (C3): 32-B slots 8.0k cycles
@@ -330,7 +337,56 @@ template <> struct KrPoll<2> {
     }
 };
 
-template <int LMAX, int ROWS>
+// One wave gathers all P slots of buffer `par` until every slot carries `tag` (8-byte loads, all loads of a pass in
+// flight); tot = sum over the slots, same order as in kr_exchange.  Bounded; false = gave up (the caller's wave 0 flags it).
+template <int LMAX>
+__device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int par, const unsigned tag, const int lane, double (&tot)[LMAX]) {
+    const int L = a.L, P = a.P;
+    const unsigned long long t0 = kr_realtime();
+    for (unsigned spins = 1;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
+        for (int q0 = 0; q0 < P; q0 += 64 * KR_POLL_CHUNKS) {
+            unsigned long long g[KR_POLL_CHUNKS][2 * LMAX];
+#pragma unroll
+            for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
+                if (q0 + 64 * c < P) {
+                    const int q = min(q0 + 64 * c + lane, P - 1);
+                    kr_gu64 *sq = (kr_gu64 *)(a.mail + ((size_t)par * P + q) * KR_SLOT_GRANULES);
+#pragma unroll
+                    for (int w = 0; w < 2 * LMAX; ++w) g[c][w] = __hip_atomic_load(sq + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
+                if (q0 + 64 * c < P) {
+                    const bool mine = (q0 + 64 * c + lane) < P;
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        if (l < L) {
+                            const unsigned long long g0 = g[c][2 * l], g1 = g[c][2 * l + 1];
+                            const bool good = ((unsigned)(g0 >> 32) == tag) & ((unsigned)(g1 >> 32) == tag);
+                            ok = ok & (good | !mine);
+                            const unsigned long long bits = (g1 << 32) | (g0 & 0xffffffffull);
+                            tot[l] += mine ? __longlong_as_double((long long)bits) : 0.0;
+                        }
+                    }
+                }
+            }
+        }
+        if (__all(ok)) break;
+        if ((spins & 63u) == 0u) {
+            const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st != 0u || kr_realtime() - t0 > KR_SPIN_TIMEOUT_TICKS) return false;
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(tot[l]);
+    return true;
+}
+
+template <int LMAX, int ROWS, int SCHED = 0>
 __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg, const bool writer,
                                             const int rowid, const double (&part)[LMAX], double (&total)[LMAX],
                                             double *spart /*[LMAX][ROWS]*/, double *stot /*[LMAX+1]*/) {
@@ -349,6 +405,49 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
     }
     __syncthreads();
 
+    if (SCHED == 1 && wave == 1 && !(P == 1 && a.world == 1)) {
+        double tot1[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            double v = 0.0;
+            if (l < L) {
+#pragma unroll
+                for (int r = 0; r < ROWS; r += 64) if (r + lane < ROWS) v += spart[l * ROWS + r + lane];
+                v = kr_wave_sum(v);
+            }
+            tot1[l] = v;
+        }
+        if (lane < 2 * L) {
+            double v = 0.0;
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) if (l == (lane >> 1)) v = tot1[l];
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            const unsigned long long *dst = a.mail + ((size_t)par * P + wg) * KR_SLOT_GRANULES + lane;
+            const unsigned long long val = ((unsigned long long)tag << 32) | half;
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
+        }
+    }
+    if (wave == 2 && a.world > 1 && wg == 0) {
+        // 4a. inter-GPU hop, sending side: wave 2 of workgroup 0 gathers the slots as well and stores the GPU total into
+        //     every rank's xmail (slot = this rank).  Its stores cross xGMI; a wave that polls after storing waits for
+        //     their acknowledgements with its first pass (vmcnt counts loads and stores together), so the polling wave 0
+        //     never stores to a peer and this wave never waits (asm stores, not counted by the compiler either).
+        if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
+        double tf[LMAX];
+        const int W = a.world;
+        if (kr_gather_slots<LMAX>(a, par, tag, lane, tf) && lane < 2 * L * W) {
+            const int r = lane / (2 * L), g = lane % (2 * L), l = g >> 1;
+            double v = 0.0;
+#pragma unroll
+            for (int ll = 0; ll < LMAX; ++ll) if (ll == l) v = tf[ll];
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            const unsigned half = (g & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            const unsigned long long *dst = a.peer_xmail[r] + ((size_t)par * W + a.rank) * (2 * LMAX) + g;
+            const unsigned long long val = ((unsigned long long)tag << 32) | half;
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(dst), "v"(val) : "memory");
+        }
+    }
     if (wave == 0) {
         bool ok_all = true;
         double tot[LMAX];
@@ -365,7 +464,8 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         if (!(P == 1 && a.world == 1)) {
             // 2. publish this workgroup's partial
             kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)par * P + wg) * KR_SLOT_GRANULES);
-            if (lane < 2 * L) {
+            if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
+            if (SCHED == 0 && lane < 2 * L) {
                 double v = 0.0;
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) if (l == (lane >> 1)) v = tot[l];
@@ -429,21 +529,10 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(tot[l]);
 
-            // 4. inter-GPU hop: workgroup 0 pushes the GPU total into every rank's xmail; every
-            //    workgroup polls its own GPU's xmail and sums the ranks in rank order.
+            // 4. inter-GPU hop, receiving side (the sending side is wave 2 of workgroup 0, above): every workgroup polls
+            //    its own GPU's xmail and sums the ranks.
             if (a.world > 1 && ok_all) {
                 const int W = a.world;
-                if (wg == 0 && lane < 2 * L * W) {
-                    const int r = lane / (2 * L), g = lane % (2 * L), l = g >> 1;
-                    double v = 0.0;
-#pragma unroll
-                    for (int ll = 0; ll < LMAX; ++ll) if (ll == l) v = tot[ll];
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                    const unsigned half = (g & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-                    kr_gu64 *dst = (kr_gu64 *)(a.peer_xmail[r] + ((size_t)par * W + a.rank) * (2 * LMAX) + g);
-                    __hip_atomic_store(dst, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
-                }
                 const unsigned long long t1 = kr_realtime();
                 spins = 0;
                 double gt[LMAX];
@@ -451,16 +540,20 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                     bool ok = true;
 #pragma unroll
                     for (int l = 0; l < LMAX; ++l) gt[l] = 0.0;
-                    for (int r = 0; r < W; ++r) {  // every lane reads every rank: rank order, identical everywhere
-                        kr_gu64 *sq = (kr_gu64 *)(a.xmail + ((size_t)par * W + r) * (2 * LMAX));
+                    {  // lane r < W reads rank r's slot (all loads in flight); fixed reduction tree below
+                        const bool mine = lane < W;
+                        kr_gu64 *sq = (kr_gu64 *)(a.xmail + ((size_t)par * W + min(lane, W - 1)) * (2 * LMAX));
+                        unsigned long long g[2 * LMAX];
+#pragma unroll
+                        for (int w = 0; w < 2 * LMAX; ++w)
+                            g[w] = (w < 2 * L) ? __hip_atomic_load(sq + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
 #pragma unroll
                         for (int l = 0; l < LMAX; ++l) {
                             if (l < L) {
-                                const unsigned long long g0 = __hip_atomic_load(sq + 2 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                const unsigned long long g1 = __hip_atomic_load(sq + 2 * l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                ok = ok && ((unsigned)(g0 >> 32) == tag) && ((unsigned)(g1 >> 32) == tag);
-                                const unsigned long long bits = (g1 << 32) | (g0 & 0xffffffffull);
-                                gt[l] += __longlong_as_double((long long)bits);
+                                const bool good = ((unsigned)(g[2 * l] >> 32) == tag) & ((unsigned)(g[2 * l + 1] >> 32) == tag);
+                                ok = ok & (good | !mine);
+                                const unsigned long long bits = (g[2 * l + 1] << 32) | (g[2 * l] & 0xffffffffull);
+                                gt[l] = mine ? __longlong_as_double((long long)bits) : 0.0;
                             }
                         }
                     }
@@ -480,7 +573,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                     __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l) tot[l] = gt[l];
+                for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(gt[l]);  // same tree on every GPU: bitwise identical totals
             }
         }
         if (lane == 0) {
@@ -500,7 +593,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 // Wave roles: wave 0 runs the exchange; the LAST wave moves states between HBM and LDS
 // (chi(t_{n+1}) prefetch, forward-storage writes); every wave takes part in the matvecs.
 // =============================================================================================
-template <int NP, int LMAX, int KT>
+template <int NP, int LMAX, int KT, int SCHED>
 __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, KT>::THREADS / 256)) void kr_sweep_update(const KrSweepArgs a) {
     using G = KrGeom<NP, LMAX, KT>;
     constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, KTILE = G::KTILE, NPP = G::NPP, NW = G::NW;
@@ -644,7 +737,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 
         // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
         double du[LMAX];
-        if (!kr_exchange<LMAX, 64>(a, n, wg, writer, rowid, part, du, spart, stot)) return;
+        if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot)) return;
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 
         // ---- pulse update (optimize.jl:351-358), identical on every workgroup ---------------
@@ -815,7 +908,8 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
 #define KR_CASE(LM, KTv)                                                                          \
     if (lmax == LM && kt == KTv) {                                                                \
         if (kind == 0) hipLaunchKernelGGL((kr_sweep_known<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else if (kind == 1) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        else if (kind == 1) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        else if (kind == 4) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
         else if (kind == 2) { kr_launch_expm<NP, LM, CB>(grid, s, a); }                              \
         else hipLaunchKernelGGL((kr_sweep_apply<NP, KTv>), dim3(grid), dim3(KrApplyGeom<NP>::THREADS), 0, s, *a);      \
         return hipGetLastError();                                                                 \

@@ -62,6 +62,7 @@ struct kr_handle {
     bool precomp = false;
     bool use_mfma = true;
     unsigned long long *mail_d = nullptr, *xmail_d = nullptr;
+    int poll_delay = -1;  // exchange schedule of the update sweep (KrSweepArgs::poll_delay), set by calibrate_exchange
     unsigned long long *peer_xmail[8]{};
     bool peers_connected = false;
     unsigned *status_d = nullptr;
@@ -360,6 +361,9 @@ static hipError_t alloc_mailbox(kr_handle *h, unsigned long long **p, size_t wor
     return dalloc(p, words);
 }
 
+static int calibrate_exchange(kr_handle *h);  // defined below, next to launch_update
+static int check_status(kr_handle *h);
+
 extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     if (out) *out = nullptr;
     if (!cfg || !out) return fail(nullptr, KR_ERR_INVALID, "kr_create: null argument");
@@ -514,6 +518,8 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     }
     CHK(hipDeviceSynchronize());
 #undef CHK
+    rc = calibrate_exchange(h);
+    if (rc != KR_OK) return bail(rc);
     *out = h;
     return KR_OK;
 }
@@ -569,7 +575,7 @@ extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
     if (!h || !info) return KR_ERR_INVALID;
     memset(info, 0, 16 * sizeof(int32_t));
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
-    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0;
+    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay;
     // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
     return KR_OK;
 }
@@ -635,6 +641,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.status = h->status_d;
     a.debug = h->debug_on ? h->debug_d : nullptr;
     a.mail = h->mail_d;
+    a.poll_delay = h->poll_delay;
     a.xmail = h->xmail_d;
     for (int r = 0; r < 8; ++r) a.peer_xmail[r] = h->peer_xmail[r];
 }
@@ -689,11 +696,12 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     return ev_mark(h, which_ev, true);
 }
 
-static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_new_dev) {
-    if (h->cfg.world > 1 && !h->peers_connected)
+static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_new_dev, int calib_steps = 0) {
+    if (h->cfg.world > 1 && !h->peers_connected && !calib_steps)
         return fail(h, KR_ERR_STATE, "world = %d but kr_ipc_connect has not been called", h->cfg.world);
     KrSweepArgs a;
     base_args(h, a);
+    if (calib_steps) { a.NT = calib_steps; a.world = 1; a.rank = 0; }  // calibration: first steps only, this GPU alone
     a.Hpack = h->Hpack_fw;
     a.eps = eps_guess_dev;
     a.init = h->psi0_d; a.store = h->store_fw ? h->Phi_d : nullptr; a.fin = h->psiT_d;
@@ -711,8 +719,57 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
         if (rc) return rc;
         HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 1, h->P, h->stream, &a));
     } else
-    HIPCHK(h, h->launch(h->LMAXv, h->KT, 1, h->P, h->stream, &a));
+    HIPCHK(h, h->launch(h->LMAXv, h->KT, (h->poll_delay >= 0 && h->NP <= 64) ? 4 : 1, h->P, h->stream, &a));  // kind 4: delayed-poll schedule
     return ev_mark(h, 2, true);
+}
+
+// The exchange of the update sweep has two schedules (kr_exchange): wave 0 publishes and polls (its first pass then also
+// waits for the store's acknowledgement), or wave 1 publishes and wave 0 starts polling after a fixed delay, so that its
+// FIRST pass already finds every tag.  The best delay is sharp (C3, P = 256: none 7.02, 0.43 us 6.96, 0.64 us 6.83, 0.85 us
+// 6.66, 1.07 us 6.87, 1.28 us 7.05 us per step) and depends on the number of workgroups and on the memory system, so it is
+// measured once per handle: a few short update sweeps (first <= 256 steps, zero states and pulses; results do not depend on
+// the schedule, only the timing does).  KROTOV_HIP_POLL_DELAY fixes the value (-1 = classic), KROTOV_HIP_CALIBRATE=0
+// skips the measurement.
+static int calibrate_exchange(kr_handle *h) {
+    const int fixed = env_int("KROTOV_HIP_POLL_DELAY", -2);
+    if (fixed != -2) { h->poll_delay = fixed; return KR_OK; }
+    // (N > 64: a step holds ~9 memory round trips of which the exchange is one: not worth 0.2 s of calibration)
+    if (h->P < 64 || h->NP > 64 || !env_int("KROTOV_HIP_CALIBRATE", 1)) return KR_OK;
+    const int L = h->cfg.L, NT = h->cfg.NT, steps = std::min(NT, 256);
+    const size_t slice = (size_t)h->Kp * h->cfg.N;
+    HIPCHK(h, hipMemsetAsync(h->X_d, 0, slice * (size_t)(steps + 1) * sizeof(double2), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->eps_a, 0, (size_t)L * NT * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->S_d, 0, (size_t)L * NT * sizeof(double), h->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    float best = 0.f;
+    int best_delay = -1, rc = KR_OK;
+    auto measure = [&](int delay) {
+        h->poll_delay = delay;
+        float tmin = 0.f;
+        for (int rep = 0; rep < 3 && rc == KR_OK; ++rep) {  // rep 0 warms up
+            if (hipEventRecord(e0, h->stream) != hipSuccess) { rc = fail(h, KR_ERR_HIP, "hipEventRecord failed"); break; }
+            rc = launch_update(h, h->eps_a, h->eps_b, steps);
+            if (rc != KR_OK) break;
+            if (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = fail(h, KR_ERR_HIP, "hipEventSynchronize failed"); break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && (tmin == 0.f || ms < tmin)) tmin = ms;
+        }
+        if (rc == KR_OK) rc = check_status(h);
+        if (rc == KR_OK && (best == 0.f || tmin < best)) { best = tmin; best_delay = delay; }
+    };
+    for (int d : {-1, 12, 16, 20, 24}) if (rc == KR_OK) measure(d);   // coarse: 0.21 us apart
+    if (rc == KR_OK && best_delay > 0) {                                // refine: 0.11 us apart
+        const int c = best_delay;
+        measure(c - 2);
+        if (rc == KR_OK) measure(c + 2);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    h->poll_delay = best_delay;
+    return rc;
 }
 
 static int check_status(kr_handle *h) {

@@ -1,0 +1,12 @@
+import sys, time, os
+sys.path.insert(0, os.getcwd())
+import krotov_jl_amd as kr
+from krotov_jl_amd import workloads as wl
+for cfg in ["C3", "C4", "C5"]:
+    p = wl.config(cfg)
+    K = p["psi0"].shape[0]
+    for cal in ["0", "1"]:
+        os.environ["KROTOV_HIP_CALIBRATE"] = cal
+        t0 = time.perf_counter(); eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K); t1 = time.perf_counter()
+        print(cfg, "calibrate", cal, "create %.1f ms" % (1e3 * (t1 - t0)), eng.info()["exchange_poll_delay"])
+        del eng
