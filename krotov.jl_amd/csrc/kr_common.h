@@ -118,7 +118,7 @@ typedef hipError_t (*kr_launch_fn)(int variant_lmax, int variant_kt, int kind, i
                                    hipStream_t stream, const KrSweepArgs *args);
 // kind: 0 = known-pulse sweep (Taylor), 1 = update sweep, 2 = batched propagator build (grid = NT),
 //       3 = known-pulse sweep with precomputed propagators, 4 = update sweep with the delayed-poll exchange schedule
-//       (N <= 64 only)
+//       (N <= 64 only), 5 / 6 = kinds 1 / 4 as kr_sweep_update<..., CAL = 1> (calibration launches)
 hipError_t kr_launch_np8(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np16(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np32(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);

@@ -593,7 +593,9 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 // Wave roles: wave 0 runs the exchange; the LAST wave moves states between HBM and LDS
 // (chi(t_{n+1}) prefetch, forward-storage writes); every wave takes part in the matvecs.
 // =============================================================================================
-template <int NP, int LMAX, int KT, int SCHED>
+// CAL = 1: the same kernel under another name for the short sweeps of calibrate_exchange (krotov_hip.hip), so that
+// profiler statistics of kr_sweep_update<..., 0> hold the caller's launches only
+template <int NP, int LMAX, int KT, int SCHED, int CAL>
 __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, KT>::THREADS / 256)) void kr_sweep_update(const KrSweepArgs a) {
     using G = KrGeom<NP, LMAX, KT>;
     constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, KTILE = G::KTILE, NPP = G::NPP, NW = G::NW;
@@ -908,8 +910,10 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
 #define KR_CASE(LM, KTv)                                                                          \
     if (lmax == LM && kt == KTv) {                                                                \
         if (kind == 0) hipLaunchKernelGGL((kr_sweep_known<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else if (kind == 1) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else if (kind == 4) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        else if (kind == 1) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        else if (kind == 4) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        else if (kind == 5) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        else if (kind == 6) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
         else if (kind == 2) { kr_launch_expm<NP, LM, CB>(grid, s, a); }                              \
         else hipLaunchKernelGGL((kr_sweep_apply<NP, KTv>), dim3(grid), dim3(KrApplyGeom<NP>::THREADS), 0, s, *a);      \
         return hipGetLastError();                                                                 \

@@ -719,7 +719,10 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
         if (rc) return rc;
         HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 1, h->P, h->stream, &a));
     } else
-    HIPCHK(h, h->launch(h->LMAXv, h->KT, (h->poll_delay >= 0 && h->NP <= 64) ? 4 : 1, h->P, h->stream, &a));  // kind 4: delayed-poll schedule
+    {   // kind 4: delayed-poll schedule; 5 / 6: the same two kernels under their calibration name (template parameter CAL)
+        const int kind = ((h->poll_delay >= 0 && h->NP <= 64) ? 4 : 1) + (calib_steps ? (h->poll_delay >= 0 ? 2 : 4) : 0);
+        HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P, h->stream, &a));
+    }
     return ev_mark(h, 2, true);
 }
 

@@ -400,3 +400,30 @@ def test_trajectories_per_team_variants(oracle_c, monkeypatch, kt):
         p = wl.dense_problem(N, NT, K, L, seed, 0.1, 2.0)
         info = _run_case(oracle_c, p, check_storage=True)
         assert info["KT"] == int(kt)
+
+
+def test_exchange_schedules_agree_bitwise(oracle_c, monkeypatch):
+    """The two schedules of the per-step exchange (wave 0 publishes and polls / publisher wave + delayed polling wave,
+    delay calibrated at kr_create) change timing only: results must agree bit for bit, and with the oracle."""
+    p = wl.dense_problem(40, 30, 80, 2, 131, 0.05, 1.0)  # NP = 64, one trajectory per workgroup: 80 workgroups
+    out = {}
+    for delay in ["-1", "0", "16", "auto"]:
+        if delay == "auto":
+            monkeypatch.delenv("KROTOV_HIP_POLL_DELAY", raising=False)
+        else:
+            monkeypatch.setenv("KROTOV_HIP_POLL_DELAY", delay)
+        eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 80)
+        info = eng.info()
+        assert info["workgroups"] >= 64
+        if delay != "auto":
+            assert info["exchange_poll_delay"] == int(delay)
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
+        out[delay] = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        eng.close()
+    for delay in ["0", "16", "auto"]:
+        for x, y in zip(out[delay], out["-1"]):
+            assert np.array_equal(x, y)
+    monkeypatch.setenv("KROTOV_HIP_POLL_DELAY", "16")
+    _run_case(oracle_c, p)
