@@ -32,6 +32,8 @@ struct KrSweepArgs {
     const double *alpha;     // [L][NT] = S[l][n] / lambda[l] (optimize.jl:354), divided once on the host
     double *eps_new;         // [L][NT]
     double *g_a_int;         // [L]
+    int xcd_group;             // row-split: the R workgroups of a trajectory have equal blockIdx % 8 (one XCD under round-robin placement)
+    int gather_delay;          // row-split all-gather: the polling wave starts after gather_delay x 128 cycles
     int poll_delay;            // exchange schedule 1 (kr_exchange): wave 0 starts polling after poll_delay x 128 cycles
     unsigned long long *mail;  // [2][P][2*LMAX] granules {tag32 | half of a double}
     unsigned long long *xmail; // [2][world][2*LMAX] inter-GPU granules (local memory, peers write)

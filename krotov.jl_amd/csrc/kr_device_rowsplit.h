@@ -53,6 +53,8 @@ struct KrGroupBox {
     unsigned long long *base;  // this tile's mailbox: [2][NP][4] granules
     unsigned tag_base;
     unsigned counter;
+    unsigned long long tpoll, npass;  // diagnostics (a.debug): cycles spent polling and number of poll passes, wave 0
+    bool local;  // all R workgroups of the tile run on ONE XCD (checked at kernel start): publish into that XCD's L2 only
 };
 
 // Publish this workgroup's NR new elements (row owners hold them) and gather the other blocks of the tile into
@@ -65,16 +67,27 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
     const unsigned tag = box.tag_base + (++box.counter);
     const int par = box.counter & 1;
     kr_gu64 *mb = (kr_gu64 *)(box.base + (size_t)par * NP * 4);
+    // Row owners put their element into the LDS vector; after a barrier WAVE 1 publishes the whole block (16-byte asm
+    // stores the compiler does not count: nobody waits for their acknowledgement) while wave 0, which therefore never
+    // stores, polls: vmcnt counts loads and stores together, and a wave that stored first waits for the acknowledgement
+    // from memory with its first poll pass (1.2-1.9 us against 0.75 us for a pass of loads alone).
     if (owner) {
-        // one 16-byte store per component: {lo32, tag, hi32, tag} = two self-validating granules
         const int e = rb * NR + il;
-        const unsigned long long br = (unsigned long long)__double_as_longlong(vr), bi = (unsigned long long)__double_as_longlong(vi);
-        kr_v4u wr, wi;
+        dst[e + e / JS] = make_double2(vr, vi);
+    }
+    __syncthreads();
+    if ((tid >> 6) == 1 && (tid & 63) < NR) {
+        const int e = rb * NR + (tid & 63);
+        const double2 v = dst[e + e / JS];
+        const unsigned long long br = (unsigned long long)__double_as_longlong(v.x), bi = (unsigned long long)__double_as_longlong(v.y);
+        kr_v4u wr, wi;  // one 16-byte store per component: {lo32, tag, hi32, tag} = two self-validating granules
         wr.x = (unsigned)br; wr.y = tag; wr.z = (unsigned)(br >> 32); wr.w = tag;
         wi.x = (unsigned)bi; wi.y = tag; wi.z = (unsigned)(bi >> 32); wi.w = tag;
         const unsigned long long *pe = (const unsigned long long *)mb + 4 * e;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(pe), "v"(wr), "v"(wi) : "memory");
-        dst[e + e / JS] = make_double2(vr, vi);  // own block goes straight to LDS
+        // local: sc0 stores stay in the XCD's L2, where the group's sc1 loads (which bypass only the vector L1) find them;
+        // otherwise sc1 stores write through to memory for readers on other XCDs
+        if (box.local) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0" :: "v"(pe), "v"(wr), "v"(wi) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(pe), "v"(wr), "v"(wi) : "memory");
     }
     // wave 0 gathers the NP - NR foreign elements: lane handles elements lane, lane + 64, ...; every load of a pass
     // is in flight before the first tag is looked at (no workgroup barrier inside the spin); 16-byte sc1 loads, the
@@ -93,7 +106,9 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
         }
         const unsigned long long *mbc = (const unsigned long long *)mb;
         kr_v4u g[KR_POLL_CHUNKS][2];
+        if (!box.local) for (int w = 0; w < a.gather_delay; ++w) __builtin_amdgcn_s_sleep(2);
         const unsigned long long t0 = kr_realtime();
+        const unsigned long long tm0 = a.debug ? __builtin_amdgcn_s_memtime() : 0;
         unsigned spins = 0;
         for (;;) {
             bool ok = true;
@@ -115,6 +130,7 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
                 }
             }
         }
+        if (a.debug) { box.tpoll += __builtin_amdgcn_s_memtime() - tm0; box.npass += spins + 1; }
         if (alive) {
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
@@ -243,7 +259,12 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     __shared__ double stot[LMAX + 1];
     __shared__ int sflag[2];
 
-    const int tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63;
+    // Workgroup -> (trajectory tile, row block).  With a.xcd_group (K % 8 == 0) the R workgroups of a tile have equal
+    // blockIdx % 8: one XCD under the dispatcher's round-robin placement, which is CHECKED below through HW_REG_XCC_ID;
+    // only then does the all-gather stay inside that XCD's L2 (speed; the other path is correct for any placement).
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tiles = a.P / R;
+    const int wg = a.xcd_group ? (((int)(blockIdx.x & 7) * (tiles >> 3) + (int)(blockIdx.x >> 3) / R) * R + (int)(blockIdx.x >> 3) % R) : (int)blockIdx.x;
     const int tile = wg / R, rb = wg % R;
     const int il = tid / JQ, jq = tid % JQ;
     const int row = rb * NR + il;
@@ -262,6 +283,29 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     box.base = a.gmail + (size_t)tile * 2 * NP * 4;
     box.tag_base = a.epoch_base2;
     box.counter = 0;
+    box.local = false; box.tpoll = 0; box.npass = 0;
+    if (a.xcd_group) {
+        // every workgroup posts {launch tag | XCC id}; wave 0 reads its R group members: local iff all ids agree
+        unsigned long long *xtab = a.gmail + (size_t)tiles * 2 * NP * 4;
+        if (tid < 64) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned ltag = a.epoch_base2 | 0x800000u;
+            if (lane == 0) __hip_atomic_store((kr_gu64 *)xtab + wg, ((unsigned long long)ltag << 32) | (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = kr_realtime();
+            bool same = false;
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load((kr_gu64 *)xtab + tile * R + (lane % R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool got = ((unsigned)(v >> 32) == ltag);
+                if (__all(got)) { same = __all((unsigned)(v & 15u) == (xcc & 15u)); break; }
+                if (kr_realtime() - t0 > KR_SPIN_TIMEOUT_TICKS / 64) break;  // never arrived: stay on the placement-independent path
+            }
+            if (lane == 0) sflag[0] = same ? 1 : 0;
+        }
+        __syncthreads();
+        box.local = (sflag[0] != 0);
+        __syncthreads();
+    }
 
     // full initial vector into LDS, own element into registers
     for (int e = tid; e < NP; e += G::THREADS) {
@@ -380,7 +424,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
             a.store[(size_t)slot * slab + kbase + row] = make_double2(pr, pim);
         }
     }
-    if (stamp && tid == 0) { a.debug[0] = tS; a.debug[1] = tD; a.debug[2] = tG; a.debug[3] = tX; a.debug[7] = nG; }
+    if (stamp && tid == 0) { a.debug[0] = tS; a.debug[1] = tD; a.debug[2] = tG; a.debug[3] = tX; a.debug[7] = nG; a.debug[5] = box.tpoll; a.debug[6] = box.npass; }
 #undef KR_STAMP
     if (a.fin && owner && row_ok) a.fin[kbase + row] = make_double2(pr, pim);
     if (UPDATE && wg == 0 && tid == 0) {

@@ -41,6 +41,7 @@ struct kr_handle {
     kr_launch_fn launch_rs = nullptr;
     unsigned long long *gmail_d = nullptr;
     size_t gmail_words = 0;
+    bool xcd_group = false;  // row-split: workgroup ids laid out so that a trajectory's R workgroups share blockIdx % 8
     unsigned launch_id = 0;
     bool store_fw = true;
     double tol = 1e-16;
@@ -459,8 +460,11 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     CHK(dalloc(&h->wg_gen_d, wg_gen.size()));
     CHK(hipMemcpy(h->wg_gen_d, wg_gen.data(), wg_gen.size() * sizeof(int), hipMemcpyHostToDevice));
     if (h->rowsplit) {
-        h->gmail_words = (size_t)cfg->K * 2 * NP * 4;
-        CHK(alloc_mailbox(h, &h->gmail_d, h->gmail_words, h->P));
+        // vector mailboxes [K][2][NP][4] + one word per workgroup (XCD ids, see kr_rowsplit_sweep); ordinary cached
+        // memory: the XCD-local path of the all-gather lives on L2 hits
+        h->gmail_words = (size_t)cfg->K * 2 * NP * 4 + (size_t)h->P;
+        h->xcd_group = (cfg->K % 8 == 0) && env_int("KROTOV_HIP_XCD_GROUP", 1) != 0;
+        CHK(dalloc(&h->gmail_d, h->gmail_words));
         CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
     }
     std::vector<double> dt(NT);
@@ -634,6 +638,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     memcpy(a.thr, h->thr, sizeof a.thr);
     a.use_mfma = h->use_mfma ? 1 : 0;
     a.gmail = h->gmail_d;
+    a.xcd_group = h->xcd_group ? 1 : 0;
     a.pack_stride = h->pack_stride;
     a.wg_gen = (h->G > 1) ? h->wg_gen_d : nullptr;
     a.nrm_dev = h->nrm_d;
@@ -642,6 +647,9 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.debug = h->debug_on ? h->debug_d : nullptr;
     a.mail = h->mail_d;
     a.poll_delay = h->poll_delay;
+    // row-split all-gather: polling starts 9 x 128 cycles (0.48 us) after the block was handed to the publishing wave;
+    // measured at C5 (forward sweep, us per step): 0 -> 32.4, 4 -> 31.5, 8 -> 30.6, 10 -> 30.4, 12 -> 31.0, 16 -> 32.8, 20 -> 34.7
+    a.gather_delay = env_int("KROTOV_HIP_GATHER_DELAY", 9);
     a.xmail = h->xmail_d;
     for (int r = 0; r < 8; ++r) a.peer_xmail[r] = h->peer_xmail[r];
 }

@@ -427,3 +427,23 @@ def test_exchange_schedules_agree_bitwise(oracle_c, monkeypatch):
             assert np.array_equal(x, y)
     monkeypatch.setenv("KROTOV_HIP_POLL_DELAY", "16")
     _run_case(oracle_c, p)
+
+
+def test_rowsplit_xcd_grouping_changes_timing_only(oracle_c, monkeypatch):
+    """K % 8 == 0: the R workgroups of a trajectory are laid out on one XCD (checked in the kernel through
+    HW_REG_XCC_ID) and all-gather through that XCD's L2; any other placement uses the write-through path.  Same bits."""
+    out = {}
+    for (N, NT, K, L, seed) in [(130, 4, 8, 1, 141), (100, 3, 16, 2, 142)]:   # R = 32 and R = 8..16
+        p = wl.dense_problem(N, NT, K, L, seed, 0.05, 2.0)
+        for grp in ["0", "1"]:
+            monkeypatch.setenv("KROTOV_HIP_XCD_GROUP", grp)
+            with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+                assert eng.info()["rowsplit_R"] > 1
+                eng.set_initial_states(p["psi0"])
+                psiT = eng.forward(p["eps"])
+                _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
+                out[grp] = (psiT,) + tuple(eng.iteration(p["eps"], chiT, p["S"], p["lam"]))
+        for x, y in zip(out["0"], out["1"]):
+            assert np.array_equal(x, y)
+        monkeypatch.setenv("KROTOV_HIP_XCD_GROUP", "1")
+        _run_case(oracle_c, p, check_storage=True)

@@ -36,9 +36,10 @@ if st[4]:
     cyc = sum(st[:4]); us = st[4] / 100.0
     print("  stamps (wg 0): matvec+dot %.0f  exchange %.0f  taylor %.0f  store %.0f cycles/step; clock %.2f GHz; %.2f us/step"
           % (st[0] / NT, st[1] / NT, st[2] / NT, st[3] / NT, cyc / us / 1e3, us / NT))
-if st[5]:
+if st[5] and not eng.info().get("rowsplit_R", 0):
     print("  taylor phase split (wg 0): setup until first round %.0f, rounds %.0f, finalize %.0f cycles/step"
           % (st[5] / NT, (st[6] - st[5]) / NT, (st[2] - st[6]) / NT))
 if eng.info().get("rowsplit_R", 0) and st[7]:
+    print("  gather poll: %.0f cycles/round, %.2f passes/round" % (st[5] / st[7], st[6] / st[7]))
     print("  row-split stamps (wg 0, last sweep): stream %.0f cycles/step, row-dot %.0f and gather %.0f cycles/round, exchange %.0f cycles/step, %d rounds"
           % (st[0] / NT, st[1] / st[7], st[2] / st[7], st[3] / NT, st[7]))
