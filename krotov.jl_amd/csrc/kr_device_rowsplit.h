@@ -152,7 +152,12 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
 //   MODE 0 (known sweeps): Heps = H0 + sum e_l H_l
 //   MODE 1 (update, phase A): Heps = H0 + sum e_l H_l, b = Heps x, a_l = H_l x        (x = LDS vector, padded)
 //   MODE 2 (update, correction): Heps += sum e_l H_l                                   (e = delta eps)
-template <int NP, int NR, int LMAX, int MODE>
+//   INC (MODE 1): start from the resident Heps instead of H0, e = eps - (pulse folded into Heps): the H0 block is not read
+// H0 and H_l never change, so between two steps only sum (eps' - eps) H_l has to be added: MODE 2 / MODE 1 + INC stream L
+// blocks instead of 1 + L (the pass is bound by the CU's L1 fill rate: 256 KB per block at N = 256, NR = 64).  Every
+// KR_RS_REFRESH-th step rebuilds Heps from H0, which bounds the accumulated rounding (<= 32 additions of 1 ulp each).
+#define KR_RS_REFRESH 32
+template <int NP, int NR, int LMAX, int MODE, bool INC = false>
 __device__ __forceinline__ void kr_rs_stream(const __amdgpu_buffer_rsrc_t rsrc, const int rb, const int L, const double (&e)[LMAX],
                                              double (&Er)[KrGeomR<NP, NR, LMAX>::JSR], double (&Ei)[KrGeomR<NP, NR, LMAX>::JSR],
                                              double2 *sHl /* LDS part [JSL][512], or unused */,
@@ -170,7 +175,7 @@ __device__ __forceinline__ void kr_rs_stream(const __amdgpu_buffer_rsrc_t rsrc, 
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
 #pragma unroll
-            for (int m = (MODE == 2 ? 1 : 0); m <= LMAX; ++m) {
+            for (int m = ((MODE == 2 || INC) ? 1 : 0); m <= LMAX; ++m) {
                 h[m][u] = make_double2(0.0, 0.0);
                 if (m <= L) {
                     // buffer load: resource (SGPRs) + one per-lane byte offset + a scalar offset per element.  With
@@ -188,7 +193,7 @@ __device__ __forceinline__ void kr_rs_stream(const __amdgpu_buffer_rsrc_t rsrc, 
         for (int u = 0; u < CH; ++u) {
             const int jj = j0 + u;
             double cr, ci;
-            if (MODE == 2) {
+            if (MODE == 2 || INC) {
                 if (jj < JSR) { cr = Er[jj < JSR ? jj : 0]; ci = Ei[jj < JSR ? jj : 0]; }
                 else { const double2 o = sHl[(jj - JSR) * T + tid]; cr = o.x; ci = o.y; }
             } else { cr = h[0][u].x; ci = h[0][u].y; }
@@ -330,6 +335,9 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     if (stamp) t_prev = __builtin_amdgcn_s_memtime();
 #define KR_STAMP(acc) if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - t_prev; t_prev = t_; }
     double Er[JSR], Ei[JSR];
+    double ecur[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) ecur[l] = 0.0;
     int cur = 0;
     for (int step = 0; step < NT; ++step) {
         const int n = (a.dir > 0) ? step : (NT - 1 - step);
@@ -339,12 +347,18 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) { eg[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0; e[l] = eg[l]; de[l] = 0.0; }
         double orr[1 + LMAX], oi[1 + LMAX];
+        const bool refresh = (step % KR_RS_REFRESH) == 0;   // rebuild H(eps) from H0; otherwise add (eps - ecur) H_l
+        double dinc[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) dinc[l] = eg[l] - ecur[l];
         if (!UPDATE) {
-            kr_rs_stream<NP, NR, LMAX, 0>(hrsrc, rb, L, eg, Er, Ei, sHl, nullptr, orr, oi);
+            if (refresh) kr_rs_stream<NP, NR, LMAX, 0>(hrsrc, rb, L, eg, Er, Ei, sHl, nullptr, orr, oi);
+            else kr_rs_stream<NP, NR, LMAX, 2>(hrsrc, rb, L, dinc, Er, Ei, sHl, nullptr, orr, oi);
             KR_STAMP(tS)
         } else {
             // phase A: H(eps_guess) block into registers, b = H(eps_g) psi, a_l = H_l psi for the own rows
-            kr_rs_stream<NP, NR, LMAX, 1>(hrsrc, rb, L, eg, Er, Ei, sHl, &sx[cur][xoff], orr, oi);
+            if (refresh) kr_rs_stream<NP, NR, LMAX, 1>(hrsrc, rb, L, eg, Er, Ei, sHl, &sx[cur][xoff], orr, oi);
+            else kr_rs_stream<NP, NR, LMAX, 1, true>(hrsrc, rb, L, dinc, Er, Ei, sHl, &sx[cur][xoff], orr, oi);
             KR_STAMP(tS)
             double part[LMAX], du[LMAX];
 #pragma unroll
@@ -370,6 +384,8 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
             kr_rs_stream<NP, NR, LMAX, 2>(hrsrc, rb, L, de, Er, Ei, sHl, nullptr, orr, oi);
             KR_STAMP(tS)
         }
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) ecur[l] = e[l];   // the pulse now folded into the resident H(eps) block
         double theta = gx.nrm[0];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) theta += fabs(e[l]) * gx.nrm[1 + l];
