@@ -136,7 +136,8 @@ int kr_read_storage(kr_handle *h, int which, int k, int n, double *out /* [N] */
 
 /* Introspection for bench / tests.  info_out (16 ints): {NP, n_workgroups, traj_per_wg, threads,
  * KT, LMAX variant, K padded, store_fw, JQ, precomputed propagators, row-split R, exchange poll delay
- * (units of 128 cycles, -1 = classic schedule; measured once by kr_create), 0...}.
+ * (units of 128 cycles, -1 = classic schedule; measured once by kr_create),
+ * Hermitian-controls kernel variant in use, 0...}.
  * kr_enable_timing(h, 1) starts a window in which every sweep-kernel launch is bracketed by HIP
  * events on the handle's stream; kr_get_timings syncs the stream and returns, per kind
  * {forward, backward, update}: {sum of kernel durations in ms, number of launches} (6 doubles). */

@@ -386,10 +386,14 @@ __device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int 
     return true;
 }
 
-template <int LMAX, int ROWS, int SCHED = 0>
+struct KrNoWork { __device__ __forceinline__ void operator()() const {} };
+
+// `work` is called exactly once by every wave while the partial sums travel (after the publishing store, before the
+// polling wave starts to poll): barrier-free work that does not depend on the total (kr_sweep_update, HERM path).
+template <int LMAX, int ROWS, int SCHED = 0, class F = KrNoWork>
 __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg, const bool writer,
                                             const int rowid, const double (&part)[LMAX], double (&total)[LMAX],
-                                            double *spart /*[LMAX][ROWS]*/, double *stot /*[LMAX+1]*/) {
+                                            double *spart /*[LMAX][ROWS]*/, double *stot /*[LMAX+1]*/, F work = F()) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, P = a.P;
     // Tags count exchange events over the life of the handle (32-bit, wrapping); the buffer parity is taken from
@@ -428,6 +432,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
         }
     }
+    if (wave != 0) work();
     if (wave == 2 && a.world > 1 && wg == 0) {
         // 4a. inter-GPU hop, sending side: wave 2 of workgroup 0 gathers the slots as well and stores the GPU total into
         //     every rank's xmail (slot = this rank).  Its stores cross xGMI; a wave that polls after storing waits for
@@ -464,7 +469,6 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         if (!(P == 1 && a.world == 1)) {
             // 2. publish this workgroup's partial
             kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)par * P + wg) * KR_SLOT_GRANULES);
-            if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
             if (SCHED == 0 && lane < 2 * L) {
                 double v = 0.0;
 #pragma unroll
@@ -474,6 +478,8 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 __hip_atomic_store(slot + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }
+            work();
+            if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
             // 3. gather all P slots (lane handles slots lane, lane+64, ...), bounded spin
             const unsigned long long t0 = kr_realtime();
             unsigned spins = 0;
@@ -575,6 +581,8 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(gt[l]);  // same tree on every GPU: bitwise identical totals
             }
+        } else {
+            work();
         }
         if (lane == 0) {
 #pragma unroll
@@ -594,8 +602,13 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 // (chi(t_{n+1}) prefetch, forward-storage writes); every wave takes part in the matvecs.
 // =============================================================================================
 // CAL = 1: the same kernel under another name for the short sweeps of calibrate_exchange (krotov_hip.hip), so that
-// profiler statistics of kr_sweep_update<..., 0> hold the caller's launches only
-template <int NP, int LMAX, int KT, int SCHED, int CAL>
+// profiler statistics of kr_sweep_update<..., 0, HERM> hold the caller's launches only.
+// HERM = 1 (every control operator H_l Hermitian, checked by kr_create): Im<chi|H_l|psi> = Im<H_l chi|psi>, and
+// c_l(n) = H_l chi(t_n) depends on stored data only.  The step then STARTS with a plain dot product of c_l(n) with psi(t_n)
+// and the exchange; forming H(eps_guess), the products b = H(eps_guess) psi and a_l = H_l psi (needed for the free first
+// application) and c_l(n+1) are computed by all waves WHILE the partial sums travel (kr_exchange's `work`), i.e. phase A
+// leaves the critical path of the step.  chi(t_{n+1}) must then be in LDS one step earlier (prefetch distance 2).
+template <int NP, int LMAX, int KT, int SCHED, int CAL, int HERM>
 __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, KT>::THREADS / 256)) void kr_sweep_update(const KrSweepArgs a) {
     using G = KrGeom<NP, LMAX, KT>;
     constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, KTILE = G::KTILE, NPP = G::NPP, NW = G::NW;
@@ -603,7 +616,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];
     __shared__ __attribute__((aligned(16))) double2 sy[2][KTILE][NPP];
     __shared__ __attribute__((aligned(16))) double2 sH0[G::H0LDS ? JS * RT : 1];
-    __shared__ __attribute__((aligned(16))) double2 sc[2][KTILE][NP];  // chi(t_n) of this tile, by step parity
+    __shared__ __attribute__((aligned(16))) double2 sc[2][KTILE][NPP];  // chi(t_k) in slot k & 1, padded like sx (it is a matvec operand when HERM)
     __shared__ double spart[LMAX * 64];
     __shared__ double stot[LMAX + 1];
 
@@ -661,8 +674,10 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
             sx[0][tq][pi_] = v;
             double2 c = make_double2(0.0, 0.0);
             if (row_ok) c = a.X[tile_base + (size_t)tq * N + i];  // chi_k(t_0)
-            sc[0][tq][i] = c;
-            sc[1][tq][i] = make_double2(0.0, 0.0);
+            sc[0][tq][pi_] = c;
+            double2 c1 = make_double2(0.0, 0.0);
+            if (HERM && row_ok && NT > 1) c1 = a.X[slab + tile_base + (size_t)tq * N + i];  // chi_k(t_1): read in step 0's window
+            sc[1][tq][pi_] = c1;
         }
     }
     if (memwave && a.store) {
@@ -674,6 +689,16 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) gint[l] = 0.0;
     __syncthreads();
+    // HERM: c_l(n) = (H_l chi(t_n))[row i], carried from the window of step n-1; c_l(0) here
+    double clr[KT][LMAX], cli[KT][LMAX];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            clr[q][l] = 0.0; cli[q][l] = 0.0;
+            if (HERM && l < L) kr_row_dot<JS, JQ>(Hr[1 + l], Hi[1 + l], &sc[0][q * SG + team][xoff], clr[q][l], cli[q][l]);
+        }
+    }
 
     // optional phase stamps of workgroup 0 (diagnostic runs only; a.debug == nullptr otherwise)
     const bool stamp = (a.debug != nullptr) && (wg == 0);
@@ -699,47 +724,85 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 if (l < L) { eg_nx[l] = a.eps[(size_t)l * NT + n + 1]; al_nx[l] = a.alpha[(size_t)l * NT + n + 1]; }
             }
         }
-        // ---- H(eps_guess) of this step (eps_guess is known in advance; exact, no drift) -----------
         double Er[JS], Ei[JS];
-#pragma unroll
-        for (int jj = 0; jj < JS; ++jj) {
-            double r, im;
-            if (G::H0LDS) { const double2 h0 = sH0[jj * RT + tt]; r = h0.x; im = h0.y; }
-            else { r = Hr[0][jj]; im = Hi[0][jj]; }
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) {
-                r = fma(eg[l], Hr[1 + l][jj], r);
-                im = fma(eg[l], Hi[1 + l][jj], im);
-            }
-            Er[jj] = r;
-            Ei[jj] = im;
-        }
-        // ---- phase A: b = H(eps_guess) psi, a_l = H_l psi and the partial sums Im<chi|H_l|psi> ----
         double a0r[KT], a0i[KT], alr[KT][LMAX], ali[KT][LMAX];
+        double cnr[KT][LMAX], cni[KT][LMAX];   // HERM: c_l(n+1)
         double part[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) part[l] = 0.0;
+        // H(eps_guess) of this step (eps_guess is known in advance; exact, no drift), b = H(eps_guess) psi, a_l = H_l psi
+        auto form_and_apply = [&]() {
 #pragma unroll
-        for (int q = 0; q < KT; ++q) {
-            const int tq = q * SG + team;
-            const double2 *src = &sx[cur][tq][xoff];
-            const double2 chi = sc[n & 1][tq][i];
-            kr_row_dot<JS, JQ>(Er, Ei, src, a0r[q], a0i[q]);
+            for (int jj = 0; jj < JS; ++jj) {
+                double r, im;
+                if (G::H0LDS) { const double2 h0 = sH0[jj * RT + tt]; r = h0.x; im = h0.y; }
+                else { r = Hr[0][jj]; im = Hi[0][jj]; }
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) {
-                alr[q][l] = 0.0; ali[q][l] = 0.0;
-                if (l < L) {
-                    kr_row_dot<JS, JQ>(Hr[1 + l], Hi[1 + l], src, alr[q][l], ali[q][l]);
-                    // Im(conj(chi) * a) = chi_r a_i - chi_i a_r ; one lane per row contributes
-                    if ((gx.present >> l) & 1u) part[l] += chi.x * ali[q][l] - chi.y * alr[q][l];
+                for (int l = 0; l < LMAX; ++l) {
+                    r = fma(eg[l], Hr[1 + l][jj], r);
+                    im = fma(eg[l], Hi[1 + l][jj], im);
+                }
+                Er[jj] = r;
+                Ei[jj] = im;
+            }
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+                const int tq = q * SG + team;
+                const double2 *src = &sx[cur][tq][xoff];
+                kr_row_dot<JS, JQ>(Er, Ei, src, a0r[q], a0i[q]);
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    alr[q][l] = 0.0; ali[q][l] = 0.0;
+                    if (l < L) kr_row_dot<JS, JQ>(Hr[1 + l], Hi[1 + l], src, alr[q][l], ali[q][l]);
                 }
             }
+        };
+        if (!HERM) {
+            // ---- phase A: b, a_l and the partial sums Im<chi|H_l|psi> ----
+            form_and_apply();
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+                const double2 chi = sc[n & 1][q * SG + team][pi_];
+                // Im(conj(chi) * a) = chi_r a_i - chi_i a_r ; one lane per row contributes
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l)
+                    if (l < L && ((gx.present >> l) & 1u)) part[l] += chi.x * ali[q][l] - chi.y * alr[q][l];
+            }
+        } else {
+            // ---- Im<H_l chi|psi> = c_r psi_i - c_i psi_r from the carried c_l(n); everything else moves into the window ----
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l)
+                    if (l < L && ((gx.present >> l) & 1u)) part[l] += clr[q][l] * pim[q] - cli[q][l] * pr[q];
+            }
         }
+        auto window = [&]() {
+            if (HERM) {
+                form_and_apply();
+#pragma unroll
+                for (int q = 0; q < KT; ++q) {
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        cnr[q][l] = 0.0; cni[q][l] = 0.0;
+                        if (l < L && n + 1 < NT)
+                            kr_row_dot<JS, JQ>(Hr[1 + l], Hi[1 + l], &sc[(n + 1) & 1][q * SG + team][xoff], cnr[q][l], cni[q][l]);
+                    }
+                }
+            }
+        };
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tA += t - t_prev; t_prev = t; }
 
         // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
         double du[LMAX];
-        if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot)) return;
+        if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot, window)) return;
+        if (HERM) {
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) { clr[q][l] = cnr[q][l]; cli[q][l] = cni[q][l]; }
+            }
+        }
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 
         // ---- pulse update (optimize.jl:351-358), identical on every workgroup ---------------
@@ -790,12 +853,12 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
             }
             if (m > 1) __syncthreads();
             // memory wave: start fetching chi(t_{n+1}); it lands while the Taylor rounds run
-            if (memwave && n + 1 < NT) {
+            if (memwave && n + 1 + HERM < NT) {
                 // unconditional loads from a clamped address: a per-lane conditional assignment would make the compiler
                 // wait for the data right here (select against the old register value) -- a full HBM latency per step
 #pragma unroll
                 for (int c = 0; c < CH; ++c)
-                        cpf[c] = a.X[(size_t)(n + 1) * slab + tile_base + min(lane + 64 * c, tile_elems - 1)];
+                        cpf[c] = a.X[(size_t)(n + 1 + HERM) * slab + tile_base + min(lane + 64 * c, tile_elems - 1)];
             }
             if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB1 += t - t_prev; }
             int w = 1;
@@ -823,9 +886,9 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 pim[q] += yi[q];
                 if (writer) sx[cur ^ 1][q * SG + team][pi_] = make_double2(pr[q], pim[q]);
             }
-            if (s == 1 && memwave && n + 1 < NT) {  // hand chi(t_{n+1}) to the row owners of the next step
+            if (s == 1 && memwave && n + 1 + HERM < NT) {  // hand chi(t_{n+1}) (HERM: chi(t_{n+2})) to the next step
 #pragma unroll
-                for (int c = 0; c < CH; ++c) if (m_tq[c] >= 0) sc[(n + 1) & 1][m_tq[c]][m_i[c]] = cpf[c];
+                for (int c = 0; c < CH; ++c) if (m_tq[c] >= 0) sc[(n + 1 + HERM) & 1][m_tq[c]][m_i[c] + m_i[c] / JS] = cpf[c];
             }
             __syncthreads();
             cur ^= 1;
@@ -849,9 +912,9 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                         if (writer) sx[cur ^ 1][tq][pi_] = make_double2(y_r, y_i);
                     }
                 }
-                if (j == 1 && sub == s - 1 && memwave && n + 1 < NT) {
+                if (j == 1 && sub == s - 1 && memwave && n + 1 + HERM < NT) {
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) if (m_tq[c] >= 0) sc[(n + 1) & 1][m_tq[c]][m_i[c]] = cpf[c];
+                    for (int c = 0; c < CH; ++c) if (m_tq[c] >= 0) sc[(n + 1 + HERM) & 1][m_tq[c]][m_i[c] + m_i[c] / JS] = cpf[c];
                 }
                 __syncthreads();
                 w ^= 1;
@@ -910,10 +973,18 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
 #define KR_CASE(LM, KTv)                                                                          \
     if (lmax == LM && kt == KTv) {                                                                \
         if (kind == 0) hipLaunchKernelGGL((kr_sweep_known<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else if (kind == 1) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else if (kind == 4) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else if (kind == 5) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else if (kind == 6) hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        else if ((kind & 15) == 1) {  /* update sweep: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 */ \
+            switch (kind >> 4) { \
+            case 0: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 0, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
+            case 1: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 0, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
+            case 2: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 1, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
+            case 3: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 1, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
+            case 4: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 0, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
+            case 5: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 0, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
+            case 6: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 1, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
+            default: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 1, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
+            } \
+        } \
         else if (kind == 2) { kr_launch_expm<NP, LM, CB>(grid, s, a); }                              \
         else hipLaunchKernelGGL((kr_sweep_apply<NP, KTv>), dim3(grid), dim3(KrApplyGeom<NP>::THREADS), 0, s, *a);      \
         return hipGetLastError();                                                                 \

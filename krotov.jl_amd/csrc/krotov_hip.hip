@@ -63,6 +63,7 @@ struct kr_handle {
     bool precomp = false;
     bool use_mfma = true;
     unsigned long long *mail_d = nullptr, *xmail_d = nullptr;
+    bool herm = false;    // every control operator Hermitian: update kernel variant HERM (kr_device.h)
     int poll_delay = -1;  // exchange schedule of the update sweep (KrSweepArgs::poll_delay), set by calibrate_exchange
     unsigned long long *peer_xmail[8]{};
     bool peers_connected = false;
@@ -442,6 +443,23 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
             nrm[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l] = norm2_bound(N, Hc + ((size_t)g * L + l) * nn);
         }
     }
+    // HERM variant of the update kernel: every control operator that enters the update integrand is exactly Hermitian
+    // (KROTOV_HIP_HERM: 0 = never, 1 = where it was measured to pay: one trajectory per team and >= 64 workgroups -- C3
+    // 6.63 -> 5.91 us per step, N = 32 / 16 / 8 at P = 256: 5.44 -> 5.07, 4.59 -> 4.38, 4.38 -> 4.26; KT = 2: 9.9 -> 10.1, KT = 4
+    // at N = 64: 17.6 -> 29 (scratch), P = 8: 4.30 -> 4.45 --, 2 = whenever the operators allow it)
+    {
+        const int mode = env_int("KROTOV_HIP_HERM", 1);
+        h->herm = (mode == 2) || (mode == 1 && h->KT == 1 && h->P >= 64 && h->NP <= 64);
+    }
+    for (int g = 0; g < G && h->herm; ++g) {
+        for (int l = 0; l < L && h->herm; ++l) {
+            if (!((present[g] >> l) & 1u)) continue;
+            const zc *M = Hc + ((size_t)g * L + l) * nn;
+            for (int c = 0; c < N && h->herm; ++c)
+                for (int r = 0; r <= c; ++r)
+                    if (M[(size_t)c * N + r] != std::conj(M[(size_t)r * N + c])) { h->herm = false; break; }
+        }
+    }
     for (int adj = 0; adj < 2; ++adj) {
         for (int g = 0; g < G; ++g)
             for (int m = 0; m <= L; ++m)
@@ -579,7 +597,7 @@ extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
     if (!h || !info) return KR_ERR_INVALID;
     memset(info, 0, 16 * sizeof(int32_t));
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
-    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay;
+    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay; info[12] = (h->herm && h->NP <= 64) ? 1 : 0;
     // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
     return KR_OK;
 }
@@ -727,8 +745,9 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
         if (rc) return rc;
         HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 1, h->P, h->stream, &a));
     } else
-    {   // kind 4: delayed-poll schedule; 5 / 6: the same two kernels under their calibration name (template parameter CAL)
-        const int kind = ((h->poll_delay >= 0 && h->NP <= 64) ? 4 : 1) + (calib_steps ? (h->poll_delay >= 0 ? 2 : 4) : 0);
+    {   // update kernel variant: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (kr_launch_np); N <= 64 only
+        int kind = 1;
+        if (h->NP <= 64) kind |= ((h->poll_delay >= 0) ? 16 : 0) | (calib_steps ? 32 : 0) | (h->herm ? 64 : 0);
         HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P, h->stream, &a));
     }
     return ev_mark(h, 2, true);
@@ -771,10 +790,11 @@ static int calibrate_exchange(kr_handle *h) {
         if (rc == KR_OK) rc = check_status(h);
         if (rc == KR_OK && (best == 0.f || tmin < best)) { best = tmin; best_delay = delay; }
     };
-    for (int d : {-1, 12, 16, 20, 24}) if (rc == KR_OK) measure(d);   // coarse: 0.21 us apart
+    for (int d : {-1, 0, 4, 8, 12, 16, 20, 24}) if (rc == KR_OK) measure(d);   // coarse: 0.21 us apart (HERM: the window work
+                                                                              // takes the place of most of the delay)
     if (rc == KR_OK && best_delay > 0) {                                // refine: 0.11 us apart
         const int c = best_delay;
-        measure(c - 2);
+        if (c >= 2) measure(c - 2);
         if (rc == KR_OK) measure(c + 2);
     }
     (void)hipEventDestroy(e0);

@@ -128,6 +128,9 @@ def config(name):
         return dense_problem(64, 1000, 1024, 2, 64001, 0.05, 5.0)
     if name == "C5":
         return liouvillian_problem()
+    if name.startswith("D:"):   # ad-hoc dense problem for the developer tools: "D:N,NT,K,L"
+        N, NT, K, L = (int(x) for x in name[2:].split(","))
+        return dense_problem(N, NT, K, L, 7000 + N, 0.05, 5.0)
     raise KeyError(name)
 
 

@@ -447,3 +447,42 @@ def test_rowsplit_xcd_grouping_changes_timing_only(oracle_c, monkeypatch):
             assert np.array_equal(x, y)
         monkeypatch.setenv("KROTOV_HIP_XCD_GROUP", "1")
         _run_case(oracle_c, p, check_storage=True)
+
+
+@pytest.mark.parametrize("kt", ["1", "2"])
+def test_hermitian_controls_path(oracle_c, monkeypatch, kt):
+    """Update-kernel variant for Hermitian control operators (Im<chi|H_l|psi> = Im<H_l chi|psi>, phase A moved into the
+    exchange window) against the general variant and the oracle, including sub-stepping, absent derivatives, several
+    trajectories per team, both exchange schedules; non-Hermitian control operators must select the general variant."""
+    monkeypatch.setenv("KROTOV_HIP_KT", kt)
+    cases = [wl.dense_problem(40, 12, 70, 2, 151, 0.05, 1.0),    # NP = 64, >= 64 workgroups at KT = 1
+             wl.dense_problem(13, 9, 300, 3, 152, 0.1, 2.0),     # NP = 16, LMAX = 4
+             wl.dense_problem(5, 7, 3, 1, 153, 0.1, 2.0),        # one workgroup
+             wl.dense_problem(24, 6, 40, 2, 154, 0.1, 50.0)]     # large updates
+    cases[3]["H0"] = cases[3]["H0"] * 30.0                        # ||H dt|| > 1: sub-steps
+    for p in cases:
+        K = p["psi0"].shape[0]
+        res = {}
+        for mode in ["0", "2"]:
+            monkeypatch.setenv("KROTOV_HIP_HERM", mode)
+            with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+                assert eng.info()["hermitian_controls_path"] == (1 if mode == "2" else 0)
+                eng.set_initial_states(p["psi0"])
+                psiT = eng.forward(p["eps"])
+                _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
+                res[mode] = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        assert _rel(res["2"][0], res["0"][0]) < TOL_PULSE
+        assert np.max(np.abs(res["2"][2] - res["0"][2])) < 1e-10
+        monkeypatch.setenv("KROTOV_HIP_HERM", "2")
+        _run_case(oracle_c, p)
+        monkeypatch.setenv("KROTOV_HIP_POLL_DELAY", "3")
+        _run_case(oracle_c, p, check_storage=False)
+        monkeypatch.delenv("KROTOV_HIP_POLL_DELAY")
+    # a non-Hermitian control operator: the general variant must be used even when the other one is forced
+    p = wl.dense_problem(12, 6, 5, 2, 155, 0.1, 2.0)
+    p["Hc"] = p["Hc"].copy()
+    p["Hc"][1, 0, 3] += 0.25
+    monkeypatch.setenv("KROTOV_HIP_HERM", "2")
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 5) as eng:
+        assert eng.info()["hermitian_controls_path"] == 0
+    _run_case(oracle_c, p)
