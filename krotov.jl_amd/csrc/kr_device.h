@@ -480,10 +480,12 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             }
             work();
             if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
-            // 3. gather all P slots (lane handles slots lane, lane+64, ...), bounded spin
+            // 3. gather all P slots (lane handles slots lane, lane+64, ...), bounded spin.  With peers on other GPUs only
+            //    the forwarding wave gathers them (one poller instead of P: the stores become visible sooner); everybody
+            //    else waits for the grand total in xmail, which includes this GPU's own contribution.
             const unsigned long long t0 = kr_realtime();
             unsigned spins = 0;
-            for (;;) {
+            for (; a.world == 1;) {
                 bool ok = true;
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
@@ -532,13 +534,16 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 }
                 __builtin_amdgcn_s_sleep(KR_POLL_SLEEP);
             }
+            if (a.world == 1) {
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(tot[l]);
+                for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(tot[l]);
+            }
 
             // 4. inter-GPU hop, receiving side (the sending side is wave 2 of workgroup 0, above): every workgroup polls
             //    its own GPU's xmail and sums the ranks.
             if (a.world > 1 && ok_all) {
                 const int W = a.world;
+                for (int w = 0; w < a.xpoll_delay; ++w) __builtin_amdgcn_s_sleep(2);
                 const unsigned long long t1 = kr_realtime();
                 spins = 0;
                 double gt[LMAX];
