@@ -18,6 +18,10 @@ def _problem(which):
     from krotov_jl_amd import workloads as wl
     if which == "rowsplit":   # N = 80 -> NP = 128, row-split kernels (several workgroups per trajectory)
         return wl.dense_problem(80, 8, 6, 1, 910, 0.05, 1.0), 6
+    if which == "four_ranks":  # world = 4 on the one GPU
+        return wl.dense_problem(12, 40, 22, 2, 912, 0.1, 1.0), 22
+    if which == "wide":        # 64 workgroups per rank: calibrated exchange schedule + Hermitian-controls kernel variant
+        return wl.dense_problem(20, 30, 256, 2, 913, 0.1, 1.0), 256
     if which == "odd_nt":     # odd N_T: consecutive launches must keep alternating the mailbox buffers
         return wl.dense_problem(16, 61, 24, 2, 911, 0.1, 1.0), 24
     return wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0), 24
@@ -25,7 +29,7 @@ def _problem(which):
 
 def _worker(rank, world, port, q, which="small"):
     sys.path.insert(0, ROOT)
-    os.environ["KROTOV_HIP_MAX_WG"] = "64"
+    os.environ["KROTOV_HIP_MAX_WG"] = "48" if world > 2 else "64"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -55,8 +59,9 @@ def _worker(rank, world, port, q, which="small"):
         raise
 
 
-@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit"])
+@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "four_ranks"])
 def test_two_ranks_one_gpu_equals_unsharded(which):
+    world = 4 if which == "four_ranks" else 2
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
     import krotov_jl_amd as kr
@@ -64,11 +69,11 @@ def test_two_ranks_one_gpu_equals_unsharded(which):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, which)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, which)) for r in range(world)]
     for pr in procs:
         pr.start()
     got = {}
-    for _ in range(2):
+    for _ in range(world):
         rank, eps, ga, psiT = q.get(timeout=180)
         assert not isinstance(eps, str), eps
         got[rank] = (eps, ga, psiT)
@@ -76,8 +81,9 @@ def test_two_ranks_one_gpu_equals_unsharded(which):
         pr.join(timeout=60)
         assert pr.exitcode == 0
     # both ranks hold the identical updated pulse, bit for bit
-    assert np.array_equal(got[0][0], got[1][0])
-    assert np.array_equal(got[0][1], got[1][1])
+    for r in range(1, world):
+        assert np.array_equal(got[0][0], got[r][0])
+        assert np.array_equal(got[0][1], got[r][1])
     # unsharded reference on one handle
     p, K = _problem(which)
     with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
@@ -88,5 +94,5 @@ def test_two_ranks_one_gpu_equals_unsharded(which):
             _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
             eps, ga, psiT = eng.iteration(eps, chiT, p["S"], p["lam"])
     assert np.max(np.abs(got[0][0] - eps)) / np.max(np.abs(eps)) < 1e-12
-    assert np.max(np.abs(np.concatenate([got[0][2], got[1][2]]) - psiT)) < 1e-11
+    assert np.max(np.abs(np.concatenate([got[r][2] for r in range(world)]) - psiT)) < 1e-11
     assert np.max(np.abs(got[0][1] - ga)) / np.max(np.abs(ga)) < 1e-10
