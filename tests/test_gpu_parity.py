@@ -261,10 +261,13 @@ def test_unsupported_sizes_fail_loudly():
     assert ei.value.code == kr._capi.KR_ERR_UNSUPPORTED
 
 
-def test_per_trajectory_generators(oracle_c):
+@pytest.mark.parametrize("herm", ["0", "2"])
+def test_per_trajectory_generators(oracle_c, monkeypatch, herm):
     """G > 1: an ensemble of different H_k (control_derivs[k][l], workspace.jl:74; optimize.jl:343).  The oracle
-    is run per generator group and the update integrands are summed over ALL trajectories by hand."""
+    is run per generator group and the update integrands are summed over ALL trajectories by hand.  Both update-kernel
+    variants (general / Hermitian control operators)."""
     import krotov_oracle as o
+    monkeypatch.setenv("KROTOV_HIP_HERM", herm)
     rng = np.random.default_rng(77)
     N, NT, L = 12, 25, 2
     G, K = 3, 8
@@ -478,6 +481,16 @@ def test_hermitian_controls_path(oracle_c, monkeypatch, kt):
         monkeypatch.setenv("KROTOV_HIP_POLL_DELAY", "3")
         _run_case(oracle_c, p, check_storage=False)
         monkeypatch.delenv("KROTOV_HIP_POLL_DELAY")
+    # without forward storage the Hermitian-controls variant gives the same pulses
+    p = cases[0]
+    outs = []
+    for store in [True, False]:
+        with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 70, store_fw=store) as eng:
+            eng.set_initial_states(p["psi0"])
+            psiT = eng.forward(p["eps"])
+            _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
+            outs.append(eng.iteration(p["eps"], chiT, p["S"], p["lam"]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2])
     # a non-Hermitian control operator: the general variant must be used even when the other one is forced
     p = wl.dense_problem(12, 6, 5, 2, 155, 0.1, 2.0)
     p["Hc"] = p["Hc"].copy()
