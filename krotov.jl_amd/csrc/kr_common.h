@@ -34,6 +34,7 @@ struct KrSweepArgs {
     double *g_a_int;         // [L]
     int xcd_group;             // row-split: the R workgroups of a trajectory have equal blockIdx % 8 (one XCD under round-robin placement)
     int xpoll_delay;           // world > 1: extra wait (x 128 cycles) before a workgroup starts polling xmail
+    int gather_delay_local;    // the same when the all-gather stays inside one XCD's L2
     int gather_delay;          // row-split all-gather: the polling wave starts after gather_delay x 128 cycles
     int poll_delay;            // exchange schedule 1 (kr_exchange): wave 0 starts polling after poll_delay x 128 cycles
     unsigned long long *mail;  // [2][P][2*LMAX] granules {tag32 | half of a double}

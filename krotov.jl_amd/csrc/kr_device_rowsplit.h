@@ -106,7 +106,7 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
         }
         const unsigned long long *mbc = (const unsigned long long *)mb;
         kr_v4u g[KR_POLL_CHUNKS][2];
-        if (!box.local) for (int w = 0; w < a.gather_delay; ++w) __builtin_amdgcn_s_sleep(2);
+        for (int w = 0; w < (box.local ? a.gather_delay_local : a.gather_delay); ++w) __builtin_amdgcn_s_sleep(2);
         const unsigned long long t0 = kr_realtime();
         const unsigned long long tm0 = a.debug ? __builtin_amdgcn_s_memtime() : 0;
         unsigned spins = 0;
