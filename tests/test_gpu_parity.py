@@ -499,3 +499,40 @@ def test_hermitian_controls_path(oracle_c, monkeypatch, kt):
     with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 5) as eng:
         assert eng.info()["hermitian_controls_path"] == 0
     _run_case(oracle_c, p)
+
+
+def test_c4_and_c5_shapes_short_grid(oracle_c):
+    """BASELINE shapes C4 (N=64, K=1024: four trajectories per team) and C5 (N=256 Liouvillian, K=64: row-split kernels,
+    four workgroups per trajectory on one XCD) on a short time grid against the oracle (shared-propagator mode)."""
+    p = wl.dense_problem(64, 6, 1024, 2, 64001, 0.05, 5.0)
+    info = _run_case(oracle_c, p, check_storage=False)
+    assert info["KT"] == 4 and info["workgroups"] == 256
+    p = wl.liouvillian_problem(n_levels=16, NT=5, K=64, seed=256001)
+    info = _run_case(oracle_c, p, check_storage=False)
+    assert info["rowsplit_R"] == 4 and info["workgroups"] == 256
+
+
+def test_full_size_properties_c5():
+    """BASELINE size C5 (N=256 Liouvillian, N_T=2000, K=64): <<chi(t_n)|rho(t_n)>> constant along the grid (the backward
+    sweep uses the true adjoint of the non-Hermitian generator), trace of every density matrix conserved, J_T decreases,
+    run-to-run bitwise reproducibility of the row-split kernels."""
+    p = wl.config("C5")
+    K, N = p["psi0"].shape
+    n_lev = int(round(np.sqrt(N)))
+    tr = np.eye(n_lev).reshape(-1)          # <<1|rho>> = trace
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        tr0 = p["psi0"] @ tr
+        assert np.max(np.abs(psiT @ tr - tr0)) < 1e-11
+        _, J0, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
+        eng.backward(p["eps"], chiT)
+        NT = p["eps"].shape[1]
+        for k in (0, 31, 63):
+            ov = [np.vdot(eng.read_storage("bw", k, n), eng.read_storage("fw", k, n)) for n in (0, NT // 3, NT)]
+            assert np.max(np.abs(np.array(ov) - ov[-1])) < 1e-11 * max(1.0, abs(ov[-1]))
+        eps_new, ga, psiT1 = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        again = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        assert np.array_equal(again[0], eps_new) and np.array_equal(again[2], psiT1)
+        assert wl.chi_and_JT(p["functional"], psiT1, p["tgt"])[1] < J0
+        assert np.max(np.abs(psiT1 @ tr - tr0)) < 1e-11
