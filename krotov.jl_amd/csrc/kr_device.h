@@ -745,7 +745,6 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         }
         double Er[JS], Ei[JS];
         double a0r[KT], a0i[KT], alr[KT][LMAX], ali[KT][LMAX];
-        double cnr[KT][LMAX], cni[KT][LMAX];   // HERM: c_l(n+1)
         double part[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) part[l] = 0.0;
@@ -803,9 +802,9 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 for (int q = 0; q < KT; ++q) {
 #pragma unroll
                     for (int l = 0; l < LMAX; ++l) {
-                        cnr[q][l] = 0.0; cni[q][l] = 0.0;
+                        // c_l(n) has been consumed by the dot products above: c_l(n+1) takes its place
                         if (l < L && n + 1 < NT)
-                            kr_row_dot<JS, JQ>(Hr[1 + l], Hi[1 + l], &sc[(n + 1) & 1][q * SG + team][xoff], cnr[q][l], cni[q][l]);
+                            kr_row_dot<JS, JQ>(Hr[1 + l], Hi[1 + l], &sc[(n + 1) & 1][q * SG + team][xoff], clr[q][l], cli[q][l]);
                     }
                 }
             }
@@ -815,13 +814,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
         double du[LMAX];
         if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot, window)) return;
-        if (HERM) {
-#pragma unroll
-            for (int q = 0; q < KT; ++q) {
-#pragma unroll
-                for (int l = 0; l < LMAX; ++l) { clr[q][l] = cnr[q][l]; cli[q][l] = cni[q][l]; }
-            }
-        }
+
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 
         // ---- pulse update (optimize.jl:351-358), identical on every workgroup ---------------
