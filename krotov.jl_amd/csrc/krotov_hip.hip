@@ -63,6 +63,7 @@ struct kr_handle {
     bool precomp = false;
     bool use_mfma = true;
     unsigned long long *mail_d = nullptr, *xmail_d = nullptr;
+    size_t mail_words = 0;
     bool herm = false;    // every control operator Hermitian: update kernel variant HERM (kr_device.h)
     int poll_delay = -1;  // exchange schedule of the update sweep (KrSweepArgs::poll_delay), set by calibrate_exchange
     unsigned long long *peer_xmail[8]{};
@@ -516,9 +517,9 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     CHK(hipMemset(h->psiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->chiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->gint_d, 0, KR_LMAX_CAP * sizeof(double)));
-    const size_t mail_words = (size_t)2 * h->P * 16;  // up to 128-B slots (KR_SLOT_GRANULES <= 16)
-    CHK(alloc_mailbox(h, &h->mail_d, mail_words, h->P));
-    CHK(hipMemset(h->mail_d, 0, mail_words * sizeof(unsigned long long)));
+    h->mail_words = (size_t)2 * h->P * 16;  // up to 128-B slots (KR_SLOT_GRANULES <= 16)
+    CHK(alloc_mailbox(h, &h->mail_d, h->mail_words, h->P));
+    CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
     CHK(dalloc(&h->debug_d, 8));
     CHK(hipMemset(h->debug_d, 0, 8 * sizeof(unsigned long long)));
     h->debug_on = env_int("KROTOV_HIP_STAMPS", 0) != 0;
@@ -685,8 +686,7 @@ static int rowsplit_prelaunch(kr_handle *h, KrSweepArgs &a) {
         h->launch_id = 1;
     }
     a.epoch_base2 = h->launch_id << 24;
-    HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
-    return KR_OK;
+    return KR_OK;   // (the status words are sticky: only check_status clears them)
 }
 
 static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool backward, const double2 *init, double2 *store, double2 *fin) {
@@ -739,7 +739,6 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     // next launch: first tag = last tag + 3 (odd step: buffer parity keeps alternating); 32-bit wrap-around is
     // harmless because every slot is rewritten every second event and tags are only compared for equality
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
-    HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
     int rc = ev_mark(h, 2, false);
     if (rc) return rc;
     if (h->rowsplit) {
@@ -769,6 +768,7 @@ static int calibrate_exchange(kr_handle *h) {
     if (h->P < 64 || h->NP > 64 || !env_int("KROTOV_HIP_CALIBRATE", 1)) return KR_OK;
     const int L = h->cfg.L, NT = h->cfg.NT, steps = std::min(NT, 256);
     const size_t slice = (size_t)h->Kp * h->cfg.N;
+    const unsigned epoch_saved = h->epoch_base;   // calibration launches must not advance the tag sequence the ranks share
     HIPCHK(h, hipMemsetAsync(h->X_d, 0, slice * (size_t)(steps + 1) * sizeof(double2), h->stream));
     HIPCHK(h, hipMemsetAsync(h->eps_a, 0, (size_t)L * NT * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->S_d, 0, (size_t)L * NT * sizeof(double), h->stream));
@@ -802,6 +802,14 @@ static int calibrate_exchange(kr_handle *h) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     h->poll_delay = best_delay;
+    // The number of calibration launches depends on timing (refinement only for best_delay > 0), so ranks would leave
+    // this function with different epoch bases and their inter-GPU tags would never match.  Restore the base and wipe the
+    // calibration tags from the intra-GPU mailbox (calibration runs with world = 1: xmail was never written).
+    h->epoch_base = epoch_saved;
+    if (rc == KR_OK) {
+        HIPCHK(h, hipMemsetAsync(h->mail_d, 0, h->mail_words * sizeof(unsigned long long), h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return rc;
 }
 
@@ -809,8 +817,16 @@ static int check_status(kr_handle *h) {
     unsigned st[KR_STATUS_WORDS] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(st, h->status_d, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (st[0] != 0)
-        return fail(h, KR_ERR_TIMEOUT, "update sweep aborted: bounded spin of the %s exchange gave up at step %u", st[1] == 2 ? "inter-GPU" : "inter-workgroup", st[2]);
+    if (st[0] != 0) {
+        // sticky until read (launches never clear it, so a failure inside a chain of *_dev calls is not lost)
+        HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const char *what = st[1] == 2 ? "inter-GPU exchange of the update sweep"
+                         : st[1] == 3 ? "row-split all-gather (the R workgroups of a trajectory)"
+                                      : "inter-workgroup exchange of the update sweep";
+        return fail(h, KR_ERR_TIMEOUT, "sweep aborted: bounded spin of the %s gave up at %s %u (status code %u); results of this call are invalid",
+                    what, st[1] == 3 ? "gather" : "step", st[2], st[1]);
+    }
     return KR_OK;
 }
 
@@ -837,6 +853,7 @@ extern "C" int kr_forward(kr_handle *h, const double *eps, double *psiT_out) {
     HIPCHK(h, hipMemcpyAsync(h->eps_a, eps, pb, hipMemcpyHostToDevice, h->stream));
     int rc = launch_known(h, 0, h->eps_a, false, h->psi0_d, h->store_fw ? h->Phi_d : nullptr, h->psiT_d);
     if (rc) return rc;
+    if (h->rowsplit) { rc = check_status(h); if (rc) return rc; }   // the row-split all-gather has bounded spins
     rc = download_states(h, psiT_out, h->psiT_d);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -854,6 +871,7 @@ extern "C" int kr_backward(kr_handle *h, const double *eps_guess, const double *
     if (rc) return rc;
     rc = launch_known(h, 1, h->eps_a, true, h->chiT_d, h->X_d, nullptr);
     if (rc) return rc;
+    if (h->rowsplit) { rc = check_status(h); if (rc) return rc; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_X = true;
     return KR_OK;
@@ -925,6 +943,8 @@ extern "C" int kr_iteration(kr_handle *h, const double *eps_guess, const double 
     if (rc) return rc;
     rc = launch_known(h, 1, h->eps_a, true, h->chiT_d, h->X_d, nullptr);
     if (rc) return rc;
+    // (no status check here: the status words are sticky -- only check_status clears them -- so a backward sweep that
+    //  gave up is reported by update_forward_locked's check after the update sweep)
     h->have_X = true;
     return update_forward_locked(h, eps_guess, S, lambda, eps_new_out, g_a_int_out, psiT_out);
 }

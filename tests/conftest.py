@@ -1,4 +1,5 @@
 import os
+import shutil
 import sys
 
 import pytest
@@ -8,17 +9,40 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "needs_hip_lib: needs libkrotov_hip.so (hipcc to build it), but no GPU")
+
+
+def _have_hipcc():
+    return os.path.exists(HIPCC) or shutil.which("hipcc") is not None
+
+
+def pytest_collection_modifyitems(config, items):
+    """CPU-only tests of the oracle and of the host logic must run on a machine without hipcc; only the tests that
+    load libkrotov_hip.so (gpu / needs_hip_lib) require the HIP build."""
+    lib = os.path.join(ROOT, "krotov.jl_amd", "lib", "libkrotov_hip.so")
+    if _have_hipcc() or os.path.exists(lib):
+        return
+    skip = pytest.mark.skip(reason="hipcc not found and libkrotov_hip.so not built")
+    for it in items:
+        if "gpu" in it.keywords or "needs_hip_lib" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session", autouse=True)
-def _native_builds():
-    """Make sure libkrotov_hip.so (hipcc, gfx950) and the C oracle exist and are current: `make` is
-    incremental, so this is a no-op when the tree was built by __graft_entry__.build()."""
-    import __graft_entry__ as ge
-    ge.build()
+def _native_builds(request):
+    """Build the C oracle always; build libkrotov_hip.so (hipcc, gfx950; `make` is incremental, a no-op when the tree
+    was built by __graft_entry__.build()) only when a collected test needs it and hipcc exists."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    needs = any(("gpu" in it.keywords or "needs_hip_lib" in it.keywords) for it in request.session.items)
+    if needs and _have_hipcc():
+        import __graft_entry__ as ge
+        ge.build()
 
 
 @pytest.fixture(scope="session")

@@ -11,6 +11,7 @@ import krotov_jl_amd as kr
 from krotov_jl_amd import _capi as capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.needs_hip_lib   # loads libkrotov_hip.so (no GPU needed); skipped where hipcc is absent
 
 
 def _declared_symbols():
