@@ -284,7 +284,7 @@ int orc_update_forward(int N, int NT, int K, int L, const double *tlist, const d
     const zc *Hcz = (const zc *)Hc;
     const zc *Xz = (const zc *)X;
     zc *psi = (zc *)malloc(sizeof(zc) * sl);
-    zc *tmp = (zc *)malloc(sizeof(zc) * N);
+    double *terms = (double *)malloc(sizeof(double) * (size_t)K);
     if (nthreads < 1) nthreads = 1;
     memcpy(psi, psi0, sizeof(zc) * sl);
     memcpy(eps_new, eps_guess, sizeof(double) * (size_t)L * NT);
@@ -296,13 +296,18 @@ int orc_update_forward(int N, int NT, int K, int L, const double *tlist, const d
         for (int l = 0; l < L; ++l) { /* optimize.jl:340-349: l outer, k inner, serial */
             double du = 0.0;
             if (!mask || mask[l]) {
+                /* the K terms Im<chi_k|mu_l|psi_k> are independent: they may be EVALUATED by several threads (each one
+                 * exactly as the serial loop would), but they are ADDED in the reference's order k = 0..K-1 */
+#pragma omp parallel for num_threads(nthreads) schedule(static)
                 for (int k = 0; k < K; ++k) {
-                    matvec(N, Hcz + (size_t)l * nn, psi + (size_t)k * N, tmp);
+                    zc t[N];
+                    matvec(N, Hcz + (size_t)l * nn, psi + (size_t)k * N, t);
                     zc d = 0;
                     const zc *chi = Xz + (size_t)n * sl + (size_t)k * N;
-                    for (int i = 0; i < N; ++i) d += conj(chi[i]) * tmp[i];
-                    du += cimag(d);
+                    for (int i = 0; i < N; ++i) d += conj(chi[i]) * t[i];
+                    terms[k] = cimag(d);
                 }
+                for (int k = 0; k < K; ++k) du += terms[k];
             }
             double alpha = S[(size_t)l * NT + n] / lam[l]; /* optimize.jl:351-358 */
             eps_new[(size_t)l * NT + n] = eps_guess[(size_t)l * NT + n] + alpha * du;
@@ -313,7 +318,7 @@ int orc_update_forward(int N, int NT, int K, int L, const double *tlist, const d
     }
     memcpy(psiT_out, psi, sizeof(zc) * sl);
     free(psi);
-    free(tmp);
+    free(terms);
     return rc;
 }
 

@@ -20,6 +20,8 @@ def _problem(which):
         return wl.dense_problem(80, 8, 6, 1, 910, 0.05, 1.0), 6
     if which == "four_ranks":  # world = 4 on the one GPU
         return wl.dense_problem(12, 40, 22, 2, 912, 0.1, 1.0), 22
+    if which == "c4_shard":    # the per-GPU shape of BASELINE config 4 on two ranks: N=64, L=2, 64 workgroups per rank (KT = 2)
+        return wl.dense_problem(64, 200, 256, 2, 64001, 0.05, 0.05), 256
     if which == "skewed":      # as "wide"; rank 0 skips the exchange calibration, rank 1 runs it (different launch counts)
         return wl.dense_problem(20, 30, 256, 2, 913, 0.1, 1.0), 256
     if which == "wide":        # 64 workgroups per rank: calibrated exchange schedule + Hermitian-controls kernel variant
@@ -51,7 +53,7 @@ def _worker(rank, world, port, q, which="small"):
         eng.set_initial_states(p["psi0"][a:b])
         psiT = eng.forward(p["eps"])
         eps = p["eps"].copy()
-        for it in range(4):
+        for it in range(1 if which == "c4_shard" else 4):
             _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"][a:b], K_global=K)
             if it == 0:
                 dist.barrier()   # later iterations run unsynchronised: ranks may be a launch apart
@@ -65,9 +67,7 @@ def _worker(rank, world, port, q, which="small"):
         raise
 
 
-@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks"])
-def test_two_ranks_one_gpu_equals_unsharded(which):
-    world = 4 if which == "four_ranks" else 2
+def _run_ranks(which, world):
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
     import krotov_jl_amd as kr
@@ -90,6 +90,16 @@ def test_two_ranks_one_gpu_equals_unsharded(which):
     for r in range(1, world):
         assert np.array_equal(got[0][0], got[r][0])
         assert np.array_equal(got[0][1], got[r][1])
+    return got
+
+
+@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks"])
+def test_two_ranks_one_gpu_equals_unsharded(which):
+    world = 4 if which == "four_ranks" else 2
+    sys.path.insert(0, ROOT)
+    import krotov_jl_amd as kr
+    from krotov_jl_amd import workloads as wl
+    got = _run_ranks(which, world)
     # unsharded reference on one handle
     p, K = _problem(which)
     with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
@@ -102,3 +112,22 @@ def test_two_ranks_one_gpu_equals_unsharded(which):
     assert np.max(np.abs(got[0][0] - eps)) / np.max(np.abs(eps)) < 1e-12
     assert np.max(np.abs(np.concatenate([got[r][2] for r in range(world)]) - psiT)) < 1e-11
     assert np.max(np.abs(got[0][1] - ga)) / np.max(np.abs(ga)) < 1e-10
+
+
+def test_c4_shard_shape_two_ranks_vs_unsharded_oracle(oracle_c):
+    """BASELINE config 4's shard shape (N=64, L=2, 64 workgroups per rank, two trajectories per team) on two ranks over
+    N_T=200 steps: the sharded update sweep (partial sums crossing ranks through the IPC mailboxes) against the UNSHARDED
+    C oracle (/root/reference/src/optimize.jl:328-370), not only against the unsharded HIP run."""
+    sys.path.insert(0, ROOT)
+    from krotov_jl_amd import workloads as wl
+    got = _run_ranks("c4_shard", 2)
+    p, K = _problem("c4_shard")
+    nth = max(1, min(16, os.cpu_count() or 1))
+    psiT_o, _ = oracle_c.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False, mode=1, nthreads=nth)
+    _, _, chiT = wl.chi_and_JT("ss", psiT_o, p["tgt"])
+    eps_o, ga_o, psiT1_o, _, _ = oracle_c.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT,
+                                                    mode=1, nthreads=nth)
+    assert np.max(np.abs(eps_o - p["eps"])) > 1e-4
+    assert np.max(np.abs(got[0][0] - eps_o)) / np.max(np.abs(eps_o)) < 1e-10
+    assert np.max(np.abs(np.concatenate([got[r][2] for r in range(2)]) - psiT1_o)) < 1e-9
+    assert np.max(np.abs(got[0][1] - ga_o)) / np.max(np.abs(ga_o)) < 1e-9
