@@ -19,6 +19,10 @@ struct KrSweepArgs {
     // generator slices, thread-major: Hpack[g][m][jj][tid_in_team] (double2), g = generator, m = 0..L
     const double2 *Hpack;
     size_t pack_stride;      // elements between two generators' packs
+    // the same matrices dense, row-major, zero-padded to 64 x 64: Hdense[g][m][row][col] (kr_device_mfma.h, NP = 64 only)
+    const double2 *Hdense;
+    size_t dense_stride;     // elements between two generators
+    int gen_div;             // kr_sweep_apply: wg_gen is indexed by blockIdx.x / gen_div (apply tiles may be narrower than update tiles)
     const int *wg_gen;       // [P] generator of each workgroup's tile (nullptr: all 0)
     const double *nrm_dev;   // [G][1 + KR_LMAX_CAP] 2-norm bounds of H0, H_1..H_L per generator
     const unsigned *present_dev; // [G] bit l set: control l has a derivative in generator g (optimize.jl:344)
@@ -129,6 +133,12 @@ hipError_t kr_launch_np32(int lmax, int kt, int kind, int grid, hipStream_t s, c
 hipError_t kr_launch_np64(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np128(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np256(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+// matrix-core update sweep for NP = 64 (kr_device_mfma.h): second argument = 4-column tiles per workgroup (2 trajectories each)
+hipError_t kr_launch_mf64_l2(int tiles, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+hipError_t kr_launch_mf64_l4(int tiles, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+static inline hipError_t kr_launch_mf64(int lmax, int tiles, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
+    return lmax <= 2 ? kr_launch_mf64_l2(tiles, kind, grid, s, a) : kr_launch_mf64_l4(tiles, kind, grid, s, a);
+}
 // row-split kernels (kr_device_rowsplit.h): second argument = rows per workgroup
 hipError_t kr_launch_rs128(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_rs256(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const double my_rinv = kr_rinv[(tid & 63) <= KR_MAX_ORDER ? (tid & 63) : 0];
     const double my_thr = kr_load_my_thr(a);
-    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x] : 0);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x / (a.gen_div > 0 ? a.gen_div : 1)] : 0);
     const int pi_ = i + i / JS;          // padded position of element i
     const int xoff = jq * (JS + 1);      // padded start of this thread's column segment
     const int N = a.N, NT = a.NT, L = a.L;

@@ -1,29 +1,32 @@
 // Update sweep on the matrix cores for NP = 64: v_mfma_f64_4x4x4_4b_f64 (four 4x4x4 blocks per instruction).
 //
-// Why this instruction: it issues every 16 cycles per SIMD from one wave with >= 2 independent accumulators
-// (tools/ubench/mfma4x4.hip: 16.1-17.0; 22 on one dependent chain) = 512 flop / 16 cycles = the fp64 peak, the same rate
-// as v_mfma_f64_16x16x4_f64 -- but its tile is 16 rows x 4 columns, so ONE workgroup needs only 2 trajectories to fill
-// it.  The register-resident VALU sweep (kr_device.h) reaches that rate only on paper: next to the 32 FMAs of a row
-// slice it spends 8 LDS reads, 12 DPP moves and 6 adds per trajectory and round, and with two or four trajectories per
-// team (K = 512 / 1024 per GPU at N = 64) it spills.
+// Why this instruction: it issues every 16-17 cycles per SIMD from one wave with >= 2 independent accumulators
+// (tools/ubench/mfma4x4.hip; 22 on one dependent chain) = 512 flop / 16 cycles = the fp64 peak, the same rate as
+// v_mfma_f64_16x16x4_f64 -- but its tile is 16 rows x 4 columns, so ONE workgroup needs only 2 trajectories to fill it.
+// The register-resident VALU sweep (kr_device.h) reaches that rate only on paper: next to the 32 FMAs of a row slice it
+// spends 8 LDS reads, 12 DPP moves and 6 adds per trajectory and round, and with two or four trajectories per team
+// (K = 512 / 1024 per GPU at N = 64) or more than two control operators it spills.
 //
 // Packed complex layout.  A 4-column tile carries 2 trajectories: column j = 2 t + c holds component c (0 = re, 1 = im) of
 // trajectory t.  For a complex matrix H = Hr + i Hi and a vector w,   packed(H w) = Hr * packed(w) + Hi * packed(i w),
-// so one complex product is two real MFMA chains into the same kind of accumulator and the result comes out packed again.
-// Every vector lives in LDS twice, as packed(w) ("Y") and packed(-i w) ("Z"); the products are taken of z = -i w, i.e.
-//      D = Hr * Z + Hi * Y = packed(-i H w),
-// which is exactly what the Taylor recurrence needs:   y_{j-1} = psi + (fs / j) (-i H y_j)   is then LANE-LOCAL (each lane
-// holds one real component of one element: no cross-lane traffic, no complex arithmetic), and so are the update integrand
-// Im<chi|H_l|psi> = sum chi_c (-i H_l psi)_c and the first-application shortcut.
+// so one complex product is two real MFMA chains and the result comes out packed again.  The products are taken of
+// z = -i w, i.e.   D = Hr * packed(-i w) + Hi * packed(w) = packed(-i H w),   which is exactly what the Taylor recurrence
+// needs:   y_{j-1} = psi + (fs / j) (-i H y_j)   is then LANE-LOCAL (each lane holds one real component of one element: no
+// cross-lane traffic, no complex arithmetic), and so are the update integrand Im<chi|H_l|psi> = sum chi_c (-i H_l psi)_c
+// and the first-application shortcut.
+// Every vector lives in LDS as an array of double2 W[row * 4 + column] = {packed(-i w), packed(w)}: the two B operands of
+// a k-block come with ONE 16-byte read.  (With two separate 8-byte arrays hipcc merges neighbouring k-blocks into
+// ds_read2_b64, which moves 128 B/clk against 256 B/clk for ds_read_b128 -- MI355X_MICROARCH.md, LDS table -- and the four
+// waves' operand reads then take as long as the MFMAs themselves: tools/ubench/mfround.hip.)
 //
-// Mapping: 256 threads = 4 waves, one per SIMD (up to 512 VGPRs per lane: the A operands of H0, H_1..H_L and H(eps), 64
-// VGPRs each, stay in registers for the whole sweep, also for L = 3, 4 -- the VALU variants for LMAX = 4 spill).  Wave w
-// owns rows 16 w .. 16 w + 15 (its four 4x4 blocks), lane l = (f0 = l & 3, blk = (l >> 2) & 3, f2 = l >> 4):
+// Mapping: 256 threads = 4 waves, one per SIMD (up to 512 registers per lane: the A operands of H_1..H_L and H(eps), 64
+// registers each, stay resident for the whole sweep, also for L = 3, 4; the drift H0 lives in LDS, 64 KB).  Wave w owns
+// rows 16 w .. 16 w + 15 (its four 4x4 blocks), lane l = (f0 = l & 3, blk = (l >> 2) & 3, f2 = l >> 4):
 //      A operand, k-block kb : H[16 w + 4 blk + f0][4 kb + f2]          (lane map measured: tools/ubench/mfma4x4.hip)
 //      B operand, k-block kb : X[4 kb + f2][column f0]                  (the same for all four blocks: LDS broadcast)
 //      D                     : Y[16 w + 4 blk + f2][column f0]
-// A round = 16 k-blocks x 2 chains = 32 MFMAs per tile and wave (512 cycles), one 8-byte LDS read per MFMA, two 8-byte LDS
-// writes per tile, one s_barrier.  TILES tiles per workgroup (KT = 2 TILES trajectories).
+// A round = 16 k-blocks x 2 chains = 32 MFMAs per tile and wave (544 cycles), one 16-byte LDS read per pair of MFMAs, two
+// 8-byte LDS writes per tile, one s_barrier.  TILES tiles per workgroup (KT = 2 TILES trajectories).
 //
 // Reference semantics: kr_sweep_update (kr_device.h), i.e. /root/reference/src/optimize.jl:321-370.
 #pragma once
@@ -35,36 +38,103 @@ __device__ __forceinline__ double kr_mfma4(const double a, const double b, const
 
 #define KR_MF_TW 256  // doubles per packed tile array: 64 rows x 4 columns
 
-// d[t] = packed(-i H w)[this lane] for the TILES tiles whose packed(-i w) / packed(w) arrays start at Z / Y
-template <int TILES>
-__device__ __forceinline__ void kr_mf_apply(const double (&Ar)[16], const double (&Ai)[16], const double *__restrict__ Z,
-                                            const double *__restrict__ Y, const int boff, double (&d)[TILES]) {
-    double pr[TILES], pi[TILES];
+// D[m][t] = packed(-i H_m w)[this lane] for NM matrices that share the B operands: W = the TILES tiles' operand arrays
+// (double2 {packed(-i w), packed(w)}, KR_MF_TW elements per tile).
+// k-blocks are visited in a per-wave ROTATED order: slot s = 0..15 stands for k-block (kb0 + s) & 15 with kb0 = 4 * wave, so
+// that slots 0..3 are the rows the wave itself produces.  All A-operand storage is in slot order (Ar[m][s], Ai[m][s] and
+// the LDS copy of the drift, A0[s * 256 + tid] = {re, im}); matrix 0 comes from A0 when LDSA0, matrices 1.. then from
+// Ar[m - 1], Ai[m - 1].
+// OWNFIRST (the Taylor rounds): the caller has just written its own rows of the vector into W and NOT yet synchronised.
+// The operands of slots 0..3 are requested at once (same-wave LDS write -> read needs no barrier), then comes the workgroup
+// barrier, then the requests for the other waves' rows -- whose latency the MFMAs of the own slots cover.
+// Software pipeline written out because hipcc sinks the LDS reads next to their MFMAs when registers are tight (2.2k
+// instead of 1.1k cycles per 64-MFMA round): the loop runs over PAIRS of slots; the operands of pair p + PD are requested
+// before the MFMAs of pair p issue, and a scheduling barrier after every pair keeps that order.
+template <int TILES, int NM, bool LDSA0, bool OWNFIRST>
+__device__ __forceinline__ void kr_mf_multi(const double2 *__restrict__ A0, const double (*__restrict__ Ar)[16],
+                                            const double (*__restrict__ Ai)[16], const double2 *__restrict__ W,
+                                            const int boff, const int kb0, double (&d)[NM][TILES]) {
+    constexpr int PER = 4 * TILES * NM;                           // MFMAs per pair of slots (16-17 cycles each)
+    constexpr int PD = (PER >= 16) ? 1 : ((PER >= 8) ? 2 : 3);    // pairs in flight ahead
+    constexpr int P0 = OWNFIRST ? 2 : PD;                         // pairs requested before the first MFMA
+    double pr[NM][TILES], pi[NM][TILES];
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) { pr[t] = 0.0; pi[t] = 0.0; }
+    for (int m = 0; m < NM; ++m)
 #pragma unroll
-    for (int kb = 0; kb < 16; ++kb) {
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            const double bz = Z[t * KR_MF_TW + kb * 16 + boff], by = Y[t * KR_MF_TW + kb * 16 + boff];
-            pr[t] = kr_mfma4(Ar[kb], bz, pr[t]);
-            pi[t] = kr_mfma4(Ai[kb], by, pi[t]);
-        }
+        for (int t = 0; t < TILES; ++t) { pr[m][t] = 0.0; pi[m][t] = 0.0; }
+    double2 b[8][TILES][2], a0[8][2];
+    // pair p = slots 2p, 2p + 1 = k-blocks kb, kb + 1 with kb = (kb0 + 2p) & 15 (kb0 is a multiple of 4: a pair never wraps)
+#define KR_MF_REQUEST(p)                                                                                               \
+    {                                                                                                                  \
+        const int pb_ = (((kb0 + 2 * (p)) & 15) << 4) + boff;                                                          \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                             \
+            _Pragma("unroll") for (int t_ = 0; t_ < TILES; ++t_) b[p][t_][u_] = W[t_ * KR_MF_TW + pb_ + 16 * u_];      \
+            if (LDSA0) a0[p][u_] = A0[(2 * (p) + u_) * 256 + threadIdx.x];                                             \
+        }                                                                                                              \
     }
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) d[t] = pr[t] + pi[t];
+    for (int p = 0; p < P0; ++p) KR_MF_REQUEST(p)
+    if (OWNFIRST) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = P0; p < P0 + PD - 1; ++p) KR_MF_REQUEST(p)
+    }
+    constexpr int AHEAD = OWNFIRST ? (P0 + PD - 1) : PD;          // pairs requested so far
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (p + AHEAD < 8) KR_MF_REQUEST(p + AHEAD)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int mr = LDSA0 ? (m > 0 ? m - 1 : 0) : m;   // register matrices follow the LDS one
+                const double ar = (LDSA0 && m == 0) ? a0[p][u].x : Ar[mr][2 * p + u];
+                const double ai = (LDSA0 && m == 0) ? a0[p][u].y : Ai[mr][2 * p + u];
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    pr[m][t] = kr_mfma4(ar, b[p][t][u].x, pr[m][t]);
+                    pi[m][t] = kr_mfma4(ai, b[p][t][u].y, pi[m][t]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef KR_MF_REQUEST
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) d[m][t] = pr[m][t] + pi[m][t];
 }
 
-template <int LMAX, int TILES, int SCHED, int CAL, int HERM>
+// one matrix from registers; OWNFIRST: see kr_mf_multi (the workgroup barrier of the round is INSIDE)
+template <int TILES, bool OWNFIRST = false>
+__device__ __forceinline__ void kr_mf_apply(const double (&Ar)[16], const double (&Ai)[16], const double2 *__restrict__ W,
+                                            const int boff, const int kb0, double (&d)[TILES]) {
+    double dd[1][TILES];
+    kr_mf_multi<TILES, 1, false, OWNFIRST>(nullptr, &Ar, &Ai, W, boff, kb0, dd);
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) d[t] = dd[0][t];
+}
+
+// this lane's component yv of a vector w -> its two places in the operand array: packed(w) here, packed(-i w) = (w_i, -w_r)
+// in the neighbouring column
+__device__ __forceinline__ void kr_mf_put(double2 *W, const int doff, const int zoff, const double zs, const double yv) {
+    ((double *)W)[2 * doff + 1] = yv;
+    ((double *)W)[2 * zoff] = zs * yv;
+}
+
+template <int LMAX, int TILES, int SCHED, int HERM>
 __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     constexpr int KT = 2 * TILES, TW = KR_MF_TW, NW = 4;
     constexpr int CH = KT;  // 16-B elements per lane when the memory wave moves a whole tile (KT * 64 / 64)
-    __shared__ __attribute__((aligned(16))) double sxY[2][TILES][TW];  // psi(t_n), packed, by parity `cur`
-    __shared__ __attribute__((aligned(16))) double sxZ[2][TILES][TW];  // -i psi(t_n)
-    __shared__ __attribute__((aligned(16))) double syY[2][TILES][TW];  // Horner vectors, ping-pong
-    __shared__ __attribute__((aligned(16))) double syZ[2][TILES][TW];
-    __shared__ __attribute__((aligned(16))) double scY[2][TILES][TW];  // chi(t_k) in slot k & 1, packed
-    __shared__ __attribute__((aligned(16))) double scZ[HERM ? 2 : 1][HERM ? TILES : 1][HERM ? TW : 4];  // -i chi (matvec operand when HERM)
+    __shared__ __attribute__((aligned(16))) double2 sx[2][TILES][TW];  // psi(t_n) as operand array, by parity `cur`
+    __shared__ __attribute__((aligned(16))) double2 sy[2][TILES][TW];  // Horner vectors, ping-pong
+    __shared__ __attribute__((aligned(16))) double2 sc[2][TILES][TW];  // chi(t_k) in slot k & 1 (a matvec operand when HERM)
+    __shared__ __attribute__((aligned(16))) double2 sH0[16 * 256];     // A operands of the drift H0, [slot][tid] = {re, im} (64 KB)
     __shared__ double spart[LMAX * NW];
     __shared__ double stot[LMAX + 1];
 
@@ -74,6 +144,7 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     const int drow = 16 * wave + 4 * blk + f2;   // row of this lane's D element
     const int dt = f0 >> 1, dc = f0 & 1;         // trajectory within the tile / component of this lane's D element
     const int boff = f2 * 4 + f0;                // B operand: X[4 kb + f2][f0]
+    const int kb0 = 4 * wave;                    // slot s of every A-operand array = k-block (kb0 + s) & 15 (kr_mf_multi)
     const int doff = drow * 4 + f0;              // where this lane's component lives in a packed array
     const int zoff = drow * 4 + (f0 ^ 1);        // -i w: (w_i, -w_r) -> this lane's component goes to the OTHER column
     const double zs = dc ? 1.0 : -1.0;           //        with this sign
@@ -87,18 +158,22 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     const int tile_elems = KT * N;
     const bool row_ok = drow < N;
 
-    // A operands of H0, H_1..H_L (dense row-major [m][64][64], zero padded): 16 k-blocks x (re, im) per matrix
-    double Hr[LMAX + 1][16], Hi[LMAX + 1][16];
+    // A operands (dense row-major [m][64][64], zero padded): 16 k-blocks x (re, im) per matrix; H_1..H_L in registers,
+    // the drift H0 in LDS
+    double Hr[LMAX][16], Hi[LMAX][16];
     {
         const double2 *Hd = a.Hdense + (size_t)gx.gen * a.dense_stride;
 #pragma unroll
-        for (int m = 0; m <= LMAX; ++m) {
+        for (int kb = 0; kb < 16; ++kb) {   // kb = slot; its k-block is kq
+            const int kq = (kb0 + kb) & 15;
+            const double2 h0 = Hd[(size_t)arow * 64 + 4 * kq + f2];
+            sH0[kb * 256 + tid] = h0;
 #pragma unroll
-            for (int kb = 0; kb < 16; ++kb) {
+            for (int l = 0; l < LMAX; ++l) {
                 double2 h = make_double2(0.0, 0.0);
-                if (m <= L) h = Hd[((size_t)m * 64 + arow) * 64 + 4 * kb + f2];
-                Hr[m][kb] = h.x;
-                Hi[m][kb] = h.y;
+                if (l < L) h = Hd[((size_t)(1 + l) * 64 + arow) * 64 + 4 * kq + f2];
+                Hr[l][kb] = h.x;
+                Hi[l][kb] = h.y;
             }
         }
     }
@@ -111,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         const int e = lane + 64 * c;
         m_ok[c] = e < tile_elems;
         const int tq = m_ok[c] ? e / N : 0, i = m_ok[c] ? e % N : 0;
-        m_pos[c] = (tq >> 1) * TW + i * 4 + 2 * (tq & 1);
+        m_pos[c] = (tq >> 1) * TW + i * 4 + 2 * (tq & 1);   // columns 2 (tq & 1) and + 1 of row i: re and im of the element
     }
     double2 cpf[CH];  // chi prefetch registers (memory wave)
 
@@ -122,16 +197,14 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         double v = 0.0;
         if (row_ok) v = ((const double *)a.init)[(tile_base + (size_t)(2 * t + dt) * N + drow) * 2 + dc];
         psi[t] = v;
-        sxY[0][t][doff] = v;
-        sxZ[0][t][zoff] = zs * v;
+        kr_mf_put(sx[0][t], doff, zoff, zs, v);
         double c0 = 0.0, c1 = 0.0;
         if (row_ok) {
             c0 = ((const double *)a.X)[(tile_base + (size_t)(2 * t + dt) * N + drow) * 2 + dc];              // chi(t_0)
             if (HERM && NT > 1) c1 = ((const double *)a.X)[(slab + tile_base + (size_t)(2 * t + dt) * N + drow) * 2 + dc];  // chi(t_1)
         }
-        scY[0][t][doff] = c0;
-        scY[1][t][doff] = c1;
-        if (HERM) { scZ[0][t][zoff] = zs * c0; scZ[1][t][zoff] = zs * c1; }
+        kr_mf_put(sc[0][t], doff, zoff, zs, c0);
+        kr_mf_put(sc[1][t], doff, zoff, zs, c1);
     }
     if (memwave && a.store) {
 #pragma unroll
@@ -148,11 +221,11 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     for (int l = 0; l < LMAX; ++l) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) cl[l][t] = 0.0;
-        if (HERM && l < L) kr_mf_apply<TILES>(Hr[1 + l], Hi[1 + l], &scZ[0][0][0], &scY[0][0][0], boff, cl[l]);
+        if (HERM && l < L) kr_mf_apply<TILES>(Hr[l], Hi[l], &sc[0][0][0], boff, kb0, cl[l]);
     }
 
     const bool stamp = (a.debug != nullptr) && (wg == 0);
-    unsigned long long tA = 0, tX = 0, tB = 0, tS = 0, t_prev = 0, rt0 = 0;
+    unsigned long long tA = 0, tX = 0, tB = 0, tS = 0, tB1 = 0, tB2 = 0, t_prev = 0, rt0 = 0;
     if (stamp) { t_prev = __builtin_amdgcn_s_memtime(); rt0 = kr_realtime(); }
     int cur = 0;
     double eg_nx[LMAX], al_nx[LMAX], dt_nx = a.dt[0];
@@ -177,12 +250,18 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         double part[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) part[l] = 0.0;
-        auto products = [&]() {
+        auto products = [&]() {   // (L is wave-uniform; LMAX = 4 covers L = 3 with a zero matrix)
+            if (L == 1) {
+                double dd[2][TILES];
+                kr_mf_multi<TILES, 2, true, false>(sH0, Hr, Hi, &sx[cur][0][0], boff, kb0, dd);
 #pragma unroll
-            for (int m = 0; m <= LMAX; ++m) {
+                for (int t = 0; t < TILES; ++t) {
+                    D[0][t] = dd[0][t]; D[1][t] = dd[1][t];
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) D[m][t] = 0.0;
-                if (m <= L) kr_mf_apply<TILES>(Hr[m], Hi[m], &sxZ[cur][0][0], &sxY[cur][0][0], boff, D[m]);
+                    for (int l = 1; l < LMAX; ++l) D[1 + l][t] = 0.0;
+                }
+            } else {
+                kr_mf_multi<TILES, 1 + LMAX, true, false>(sH0, Hr, Hi, &sx[cur][0][0], boff, kb0, D);
             }
         };
         if (!HERM) {
@@ -190,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
             products();
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
-                const double chc = scY[n & 1][t][doff];
+                const double chc = sc[n & 1][t][doff].y;
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l)
                     if (l < L && ((gx.present >> l) & 1u)) part[l] = fma(chc, D[1 + l][t], part[l]);
@@ -212,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l)
                     if (l < L && n + 1 < NT)
-                        kr_mf_apply<TILES>(Hr[1 + l], Hi[1 + l], &scZ[(n + 1) & 1][0][0], &scY[(n + 1) & 1][0][0], boff, cl[l]);
+                        kr_mf_apply<TILES>(Hr[l], Hi[l], &sc[(n + 1) & 1][0][0], boff, kb0, cl[l]);
             }
         };
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tA += t - t_prev; t_prev = t; }
@@ -252,57 +331,61 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
             for (int l = 0; l < LMAX; ++l) w = fma(e[l], D[1 + l][t], w);
             v[t] = fs * w;
             y[t] = v[t];
-            if (m > 1) { syY[0][t][doff] = v[t]; syZ[0][t][zoff] = zs * v[t]; }
+            if (m > 1) kr_mf_put(sy[0][t], doff, zoff, zs, v[t]);
         }
         // A operands of H(eps_new)
         double Er[16], Ei[16];
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
-            double r = Hr[0][kb], im = Hi[0][kb];
+            const double2 h0 = sH0[kb * 256 + tid];
+            double r = h0.x, im = h0.y;
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) { r = fma(e[l], Hr[1 + l][kb], r); im = fma(e[l], Hi[1 + l][kb], im); }
+            for (int l = 0; l < LMAX; ++l) { r = fma(e[l], Hr[l][kb], r); im = fma(e[l], Hi[l][kb], im); }
             Er[kb] = r;
             Ei[kb] = im;
         }
-        if (m > 1) __syncthreads();
         // memory wave: start fetching chi(t_{n+1}) (HERM: chi(t_{n+2})); it lands while the Taylor rounds run
         if (memwave && n + 1 + HERM < NT) {
 #pragma unroll
             for (int c = 0; c < CH; ++c)
                 cpf[c] = a.X[(size_t)(n + 1 + HERM) * slab + tile_base + min(lane + 64 * c, tile_elems - 1)];
         }
+        // Rounds j = m .. 2.  Every wave has written its own rows of the current Horner vector; the workgroup barrier of the
+        // round sits inside kr_mf_apply<.., OWNFIRST> (behind the requests for the wave's own rows).  No hazard on the
+        // ping-pong buffers: a wave writes buffer wb in round j only after that barrier, which the others reach after their
+        // reads of the same buffer in round j + 1.
+        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB1 += t - t_prev; }
         int wb = 1;
         for (int j = m; j >= 2; --j) {
             const double f = fs * kr_rinv_lane(my_rinv, j);
             double d[TILES];
-            kr_mf_apply<TILES>(Er, Ei, &syZ[wb ^ 1][0][0], &syY[wb ^ 1][0][0], boff, d);
+            kr_mf_apply<TILES, true>(Er, Ei, &sy[wb ^ 1][0][0], boff, kb0, d);   // (own rows first: 1016 -> 969 cycles per round at one tile, a wash at two)
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
                 y[t] = fma(f, d[t], v[t]);
-                if (j > 2) { syY[wb][t][doff] = y[t]; syZ[wb][t][zoff] = zs * y[t]; }
+                if (j > 2) kr_mf_put(sy[wb][t], doff, zoff, zs, y[t]);
             }
-            if (j > 2) __syncthreads();
             wb ^= 1;
         }
+        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB2 += t - t_prev; }
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             psi[t] += y[t];
-            sxY[cur ^ 1][t][doff] = psi[t];
-            sxZ[cur ^ 1][t][zoff] = zs * psi[t];
+            kr_mf_put(sx[cur ^ 1][t], doff, zoff, zs, psi[t]);
         }
-        auto hand_over_chi = [&]() {   // chi(t_{n+1}) (HERM: chi(t_{n+2})) from the prefetch registers into LDS
-            if (memwave && n + 1 + HERM < NT) {
-                const int par = (n + 1 + HERM) & 1;
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    if (m_ok[c]) {
-                        *(double2 *)(&scY[par][0][0] + m_pos[c]) = cpf[c];
-                        if (HERM) *(double2 *)(&scZ[par][0][0] + m_pos[c]) = make_double2(cpf[c].y, -cpf[c].x);
-                    }
-                }
-            }
-        };
-        if (s == 1) hand_over_chi();
+        // chi(t_{n+1}) (HERM: chi(t_{n+2})) from the prefetch registers into LDS (a macro, not a lambda: captured by
+        // reference the prefetch registers would become a stack array)
+#define KR_MF_HAND_OVER_CHI()                                                                                          \
+        if (memwave && n + 1 + HERM < NT) {                                                                            \
+            const int par = (n + 1 + HERM) & 1;                                                                        \
+            _Pragma("unroll") for (int c = 0; c < CH; ++c) {                                                           \
+                if (m_ok[c]) {   /* columns re, im of the element: {(-i chi)_c, chi_c} */                             \
+                    (&sc[par][0][0])[m_pos[c]] = make_double2(cpf[c].y, cpf[c].x);                                     \
+                    (&sc[par][0][0])[m_pos[c] + 1] = make_double2(-cpf[c].x, cpf[c].y);                                \
+                }                                                                                                      \
+            }                                                                                                          \
+        }
+        if (s == 1) { KR_MF_HAND_OVER_CHI() }
         __syncthreads();
         cur ^= 1;
         for (int sub = 1; sub < s; ++sub) {  // further sub-steps (only when ||H dt|| > KR_THETA_MAX): plain Horner from psi
@@ -310,33 +393,34 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
             for (int j = m; j >= 1; --j) {
                 const double f = fs * kr_rinv_lane(my_rinv, j);
                 double d[TILES];
-                if (j == m) kr_mf_apply<TILES>(Er, Ei, &sxZ[cur][0][0], &sxY[cur][0][0], boff, d);
-                else kr_mf_apply<TILES>(Er, Ei, &syZ[w2 ^ 1][0][0], &syY[w2 ^ 1][0][0], boff, d);
+                if (j == m) kr_mf_apply<TILES>(Er, Ei, &sx[cur][0][0], boff, kb0, d);
+                else kr_mf_apply<TILES>(Er, Ei, &sy[w2 ^ 1][0][0], boff, kb0, d);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     const double yn = fma(f, d[t], psi[t]);
-                    if (j > 1) { syY[w2][t][doff] = yn; syZ[w2][t][zoff] = zs * yn; }
-                    else { psi[t] = yn; sxY[cur ^ 1][t][doff] = yn; sxZ[cur ^ 1][t][zoff] = zs * yn; }
+                    if (j > 1) kr_mf_put(sy[w2][t], doff, zoff, zs, yn);
+                    else { psi[t] = yn; kr_mf_put(sx[cur ^ 1][t], doff, zoff, zs, yn); }
                 }
-                if (j == 1 && sub == s - 1) hand_over_chi();
+                if (j == 1 && sub == s - 1) { KR_MF_HAND_OVER_CHI() }
                 __syncthreads();
                 w2 ^= 1;
             }
             cur ^= 1;
         }
+#undef KR_MF_HAND_OVER_CHI
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB += t - t_prev; t_prev = t; }
 
         // memory wave: forward storage slot n+1 <- psi(t_{n+1}) (coalesced 16-B stores from LDS)
         if (memwave && a.store) {
 #pragma unroll
             for (int c = 0; c < CH; ++c)
-                if (m_ok[c]) a.store[(size_t)(n + 1) * slab + tile_base + lane + 64 * c] = *(const double2 *)(&sxY[cur][0][0] + m_pos[c]);
+                if (m_ok[c]) a.store[(size_t)(n + 1) * slab + tile_base + lane + 64 * c] = make_double2((&sx[cur][0][0])[m_pos[c]].y, (&sx[cur][0][0])[m_pos[c] + 1].y);
         }
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tS += t - t_prev; t_prev = t; }
     }
     if (stamp && tid == 0) {
         a.debug[0] = tA; a.debug[1] = tX; a.debug[2] = tB; a.debug[3] = tS;
-        a.debug[4] = kr_realtime() - rt0; a.debug[5] = 0; a.debug[6] = 0;
+        a.debug[4] = kr_realtime() - rt0; a.debug[5] = tB1; a.debug[6] = tB2;
     }
     if (a.fin && row_ok) {
 #pragma unroll
@@ -349,25 +433,25 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     }
 }
 
-// kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (as kr_launch_np); tiles = trajectories per workgroup / 2
-static hipError_t kr_launch_mfma64(int lmax, int tiles, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
+// kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (as kr_launch_np; the CAL bit is ignored: calibration launches run the same
+// kernel); tiles = trajectories per workgroup / 2.  One translation unit per LMAX (kr_mf64_l2.hip, kr_mf64_l4.hip).
+template <int LM>
+static hipError_t kr_launch_mfma64(int tiles, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
     if ((kind & 15) != 1) return hipErrorInvalidValue;
-#define KR_CASE_M(LM, TL)                                                                                          \
-    if (lmax == LM && tiles == TL) {                                                                               \
-        switch (kind >> 4) {                                                                                       \
-        case 0: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 0, 0>), dim3(grid), dim3(256), 0, s, *a); break;      \
-        case 1: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 0, 0>), dim3(grid), dim3(256), 0, s, *a); break;      \
-        case 2: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 1, 0>), dim3(grid), dim3(256), 0, s, *a); break;      \
-        case 3: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 1, 0>), dim3(grid), dim3(256), 0, s, *a); break;      \
-        case 4: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 0, 1>), dim3(grid), dim3(256), 0, s, *a); break;      \
-        case 5: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 0, 1>), dim3(grid), dim3(256), 0, s, *a); break;      \
-        case 6: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 1, 1>), dim3(grid), dim3(256), 0, s, *a); break;      \
-        default: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 1, 1>), dim3(grid), dim3(256), 0, s, *a); break;     \
-        }                                                                                                          \
+    const int sched = (kind >> 4) & 1, herm = (kind >> 6) & 1;
+#define KR_CASE_M(TL)                                                                                              \
+    if (tiles == TL) {                                                                                             \
+        if (!sched && !herm) hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 0>), dim3(grid), dim3(256), 0, s, *a);    \
+        else if (sched && !herm) hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 0>), dim3(grid), dim3(256), 0, s, *a); \
+        else if (!sched && herm) hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 1>), dim3(grid), dim3(256), 0, s, *a); \
+        else hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 1>), dim3(grid), dim3(256), 0, s, *a);                    \
         return hipGetLastError();                                                                                  \
     }
-    KR_CASE_M(2, 1) KR_CASE_M(2, 2) KR_CASE_M(2, 4)
-    KR_CASE_M(4, 1) KR_CASE_M(4, 2) KR_CASE_M(4, 4)
+#ifdef KR_MF_ONLY_TILES
+    KR_CASE_M(KR_MF_ONLY_TILES)
+#else
+    KR_CASE_M(1) KR_CASE_M(2)   // (4 tiles: the six vector arrays + H0 exceed the CU's LDS and the accumulators spill)
+#endif
 #undef KR_CASE_M
     return hipErrorInvalidValue;
 }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
 // ---- known-pulse sweep with precomputed propagators: one round per step ---------------------------
 template <int NP, int KT>
 __global__ __launch_bounds__((KrApplyGeom<NP>::THREADS), (KrApplyGeom<NP>::THREADS / 256)) void kr_sweep_apply(const KrSweepArgs a) {
-    const double2 *__restrict__ Upack = a.U + (size_t)(a.wg_gen ? a.wg_gen[blockIdx.x] : 0) * a.NT * NP * NP;
+    const double2 *__restrict__ Upack = a.U + (size_t)(a.wg_gen ? a.wg_gen[blockIdx.x / (a.gen_div > 0 ? a.gen_div : 1)] : 0) * a.NT * NP * NP;
     using GA = KrApplyGeom<NP>;
     constexpr int JQ = GA::JQA, JS = GA::JS, RT = GA::RT, SG = GA::SG, KTILE = SG * KT, NPP = NP + JQ, NW = GA::THREADS / 64;
     constexpr int CH = (KTILE * NP + 63) / 64;

@@ -62,6 +62,10 @@ struct kr_handle {
     double2 *U_d = nullptr;   // precomputed step propagators of the known-pulse sweeps (N <= 64), or nullptr
     bool precomp = false;
     bool use_mfma = true;
+    // update sweep on the matrix cores (kr_device_mfma.h, NP = 64): KT = 2 * tiles trajectories per 256-thread workgroup
+    bool mfma_sweep = false;
+    double2 *Hdense_fw = nullptr;
+    size_t dense_stride = 0;
     unsigned long long *mail_d = nullptr, *xmail_d = nullptr;
     size_t mail_words = 0;
     bool herm = false;    // every control operator Hermitian: update kernel variant HERM (kr_device.h)
@@ -287,9 +291,23 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
         for (int g = 0; g < h->G; ++g) t += (count[g] + h->SG * ktv - 1) / (h->SG * ktv);
         return t;
     };
+    const int kt_forced = kt;
     if (kt == 0) {
         kt = 1;
         while (kt < 4 && tiles_for(kt) > maxwg) kt <<= 1;
+    }
+    // NP = 64: the update sweep runs on the matrix cores (v_mfma_f64_4x4x4_4b_f64: 2 trajectories fill a tile) whenever
+    // the vector kernel would carry several trajectories per team or more than two control slices (both spill there).
+    // KROTOV_HIP_MFMA_SWEEP = 0 never / 1 always / unset: that rule.
+    if (NP == 64) {
+        const int mf = env_int("KROTOV_HIP_MFMA_SWEEP", -1);
+        const bool want = (mf == 1) || (mf == -1 && (kt >= 2 || h->LMAXv == 4 || tiles_for(kt) > maxwg) && kt_forced != 1);
+        if (want && kt_forced != 1) {
+            int ktm = (kt_forced >= 2) ? kt_forced : 2;
+            while (ktm < 4 && kt_forced == 0 && tiles_for(ktm) > maxwg) ktm <<= 1;
+            h->mfma_sweep = true;
+            kt = ktm;
+        }
     }
     h->KT = kt;
     h->KTILE = h->SG * kt;
@@ -323,7 +341,7 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
-                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d};
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -450,7 +468,10 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     // at N = 64: 17.6 -> 29 (scratch), P = 8: 4.30 -> 4.45 --, 2 = whenever the operators allow it)
     {
         const int mode = env_int("KROTOV_HIP_HERM", 1);
-        h->herm = (mode == 2) || (mode == 1 && h->KT == 1 && h->P >= 64 && h->NP <= 64);
+        // (matrix-core sweep: with one tile per workgroup the window hides phase A -- K = 512: 8.0k against ~8.9k cycles for
+        //  dot + exchange --, with two tiles its five products outlast the exchange: C4 11.74 vs 11.35 us per step)
+        h->herm = (mode == 2) || (mode == 1 && (h->mfma_sweep ? h->KT == 2 : h->KT == 1) && h->P >= 64 && h->NP <= 64);
+        if (h->mfma_sweep && h->LMAXv == 4 && h->KT == 4) h->herm = false;   // that instantiation spills (212 B): general variant
     }
     for (int g = 0; g < G && h->herm; ++g) {
         for (int l = 0; l < L && h->herm; ++l) {
@@ -471,6 +492,19 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
                 else pack_generator(N, NP, h->JQ, M, adj != 0, dst);
             }
         CHK(hipMemcpy(adj ? h->Hpack_bw : h->Hpack_fw, pack.data(), pack_elems * sizeof(double2), hipMemcpyHostToDevice));
+    }
+    if (h->mfma_sweep) {   // dense row-major copies, zero-padded to 64 x 64, for the A operands of the matrix-core sweep
+        h->dense_stride = (size_t)(1 + L) * 64 * 64;
+        std::vector<double2> dense(h->dense_stride * G, make_double2(0.0, 0.0));
+        for (int g = 0; g < G; ++g)
+            for (int m = 0; m <= L; ++m) {
+                const zc *M = (m == 0) ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn;
+                double2 *dst = dense.data() + (size_t)g * h->dense_stride + (size_t)m * 64 * 64;
+                for (int i = 0; i < N; ++i)
+                    for (int j = 0; j < N; ++j) { const zc v = M[i + (size_t)j * N]; dst[(size_t)i * 64 + j] = make_double2(v.real(), v.imag()); }
+            }
+        CHK(dalloc(&h->Hdense_fw, dense.size()));
+        CHK(hipMemcpy(h->Hdense_fw, dense.data(), dense.size() * sizeof(double2), hipMemcpyHostToDevice));
     }
     CHK(dalloc(&h->nrm_d, nrm.size()));
     CHK(hipMemcpy(h->nrm_d, nrm.data(), nrm.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -598,7 +632,8 @@ extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
     if (!h || !info) return KR_ERR_INVALID;
     memset(info, 0, 16 * sizeof(int32_t));
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
-    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay; info[12] = (h->herm && h->NP <= 64) ? 1 : 0;
+    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay; info[12] = (h->herm && h->NP <= 64) ? 1 : 0; info[13] = h->mfma_sweep ? 1 : 0;
+    if (h->mfma_sweep) info[3] = 256;
     // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
     return KR_OK;
 }
@@ -659,6 +694,9 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.gmail = h->gmail_d;
     a.xcd_group = h->xcd_group ? 1 : 0;
     a.pack_stride = h->pack_stride;
+    a.Hdense = h->Hdense_fw;
+    a.dense_stride = h->dense_stride;
+    a.gen_div = 1;
     a.wg_gen = (h->G > 1) ? h->wg_gen_d : nullptr;
     a.nrm_dev = h->nrm_d;
     a.present_dev = h->present_d;
@@ -708,7 +746,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         HIPCHK(h, h->launch(h->LMAXv, h->KT, 2, h->cfg.NT * h->G, h->stream, &a));
         // The apply sweep is bound by streaming U_n (NP^2 * 16 B per workgroup per step) from L2: with a shared
         // generator, wider tiles (more trajectories per workgroup, fewer workgroups) cut that traffic.
-        int kt_apply = h->KT;
+        int kt_apply = std::min(h->KT, 4);   // (KT = 8 exists only for the matrix-core update sweep)
         if (h->G == 1) {
             const int want = env_int("KROTOV_HIP_APPLY_KT", 0);
             for (int cand : {4, 2}) {
@@ -717,9 +755,13 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
                 if (pick && h->Kp % (h->SG * cand) == 0) { kt_apply = cand; break; }
             }
         }
+        a.gen_div = h->KT / kt_apply;   // apply tiles per update tile (wg_gen is indexed by update tile)
+        if (a.gen_div < 1) a.gen_div = 1;
         HIPCHK(h, h->launch(h->LMAXv, kt_apply, 3, h->Kp / (h->SG * kt_apply), h->stream, &a));
     } else {
-        HIPCHK(h, h->launch(h->LMAXv, h->KT, 0, h->P, h->stream, &a));
+        const int kt_known = std::min(h->KT, 4);   // (KT = 8 exists only for the matrix-core update sweep)
+        a.gen_div = h->KT / kt_known;
+        HIPCHK(h, h->launch(h->LMAXv, kt_known, 0, h->Kp / (h->SG * kt_known), h->stream, &a));
     }
     return ev_mark(h, which_ev, true);
 }
@@ -749,7 +791,8 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     {   // update kernel variant: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (kr_launch_np); N <= 64 only
         int kind = 1;
         if (h->NP <= 64) kind |= ((h->poll_delay >= 0) ? 16 : 0) | (calib_steps ? 32 : 0) | (h->herm ? 64 : 0);
-        HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P, h->stream, &a));
+        if (h->mfma_sweep) HIPCHK(h, kr_launch_mf64(h->LMAXv, h->KT / 2, kind, h->P, h->stream, &a));
+        else HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P, h->stream, &a));
     }
     return ev_mark(h, 2, true);
 }

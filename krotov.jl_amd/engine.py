@@ -205,7 +205,7 @@ class HipEngine:
     def info(self):
         a = (C.c_int32 * 16)()
         self._chk(self._lib.kr_get_info(self._h, a))
-        keys = ["NP", "workgroups", "traj_per_wg", "threads", "KT", "LMAX", "K_padded", "store_fw", "JQ", "precomputed_propagators", "rowsplit_R", "exchange_poll_delay", "hermitian_controls_path"]
+        keys = ["NP", "workgroups", "traj_per_wg", "threads", "KT", "LMAX", "K_padded", "store_fw", "JQ", "precomputed_propagators", "rowsplit_R", "exchange_poll_delay", "hermitian_controls_path", "matrix_core_sweep"]
         return {k: int(a[i]) for i, k in enumerate(keys)}
 
     # multi-GPU wiring

@@ -536,3 +536,70 @@ def test_full_size_properties_c5():
         assert np.array_equal(again[0], eps_new) and np.array_equal(again[2], psiT1)
         assert wl.chi_and_JT(p["functional"], psiT1, p["tgt"])[1] < J0
         assert np.max(np.abs(psiT1 @ tr - tr0)) < 1e-11
+
+
+@pytest.mark.parametrize("herm", ["0", "2"])
+def test_matrix_core_sweep_variants(oracle_c, monkeypatch, herm):
+    """The update sweep on the matrix cores (kr_device_mfma.h: v_mfma_f64_4x4x4_4b_f64, two trajectories per 4-column tile)
+    forced for every NP = 64 shape: ragged K (half-empty tiles), N < 64 (zero padding), L = 1..4 (LMAX = 4 keeps five
+    operand sets in registers), one and two tiles per workgroup, sub-stepping, non-Hermitian drift, absent derivatives,
+    per-trajectory generators, both exchange schedules, no forward storage -- general and Hermitian-controls variants."""
+    monkeypatch.setenv("KROTOV_HIP_MFMA_SWEEP", "1")
+    monkeypatch.setenv("KROTOV_HIP_HERM", herm)
+    rng = np.random.default_rng(2024)
+    for (N, NT, K, L, seed, kt) in [(64, 9, 1, 1, 201, "0"), (64, 7, 5, 2, 202, "0"), (40, 8, 7, 3, 203, "0"), (33, 6, 3, 4, 204, "0"),
+                                    (64, 6, 9, 2, 205, "4"), (50, 5, 6, 4, 206, "4"), (64, 5, 300, 2, 207, "0")]:
+        monkeypatch.setenv("KROTOV_HIP_KT", kt)
+        p = wl.dense_problem(N, NT, K, L, seed, 0.05, 0.5)
+        info = _run_case(oracle_c, p, check_storage=(K < 20))
+        assert info["NP"] == 64 and info["threads"] == 256 and info["KT"] in (2, 4)
+        assert info["hermitian_controls_path"] == (1 if herm == "2" and not (L > 2 and info["KT"] == 4) else 0)
+    monkeypatch.setenv("KROTOV_HIP_KT", "0")
+    # ||H dt|| ~ 5: every step is sub-stepped
+    p = wl.dense_problem(64, 5, 6, 2, 208, 0.1, 20.0)
+    p["H0"] = p["H0"] * 50.0
+    _run_case(oracle_c, p)
+    # non-Hermitian drift and control operator (the Hermitian-controls variant must not be selected), non-uniform grid
+    p = wl.dense_problem(48, 12, 5, 2, 209, 0.05, 0.5)
+    p["H0"] = p["H0"] - 0.05j * np.diag(rng.uniform(0, 1, 48)) + 0.02 * rng.normal(size=(48, 48))
+    p["Hc"] = p["Hc"].copy()
+    p["Hc"][0, 1, 7] += 0.3
+    p["tlist"] = np.cumsum(np.r_[0.0, rng.uniform(0.02, 0.08, 12)])
+    info = _run_case(oracle_c, p)
+    assert info["hermitian_controls_path"] == 0
+    # delayed-poll exchange schedule
+    monkeypatch.setenv("KROTOV_HIP_POLL_DELAY", "5")
+    _run_case(oracle_c, wl.dense_problem(64, 6, 8, 2, 210, 0.05, 0.5), check_storage=False)
+    monkeypatch.delenv("KROTOV_HIP_POLL_DELAY")
+    # absent derivative + no forward storage
+    p = wl.dense_problem(64, 8, 6, 2, 211, 0.05, 0.5)
+    mask = np.array([0, 1], np.uint8)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 6, hc_present=mask, store_fw=False) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+        eps_new, ga, psiT1 = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+    X = oracle_c.backward(p["H0"], p["Hc"], p["tlist"], p["eps"], chiT)
+    eps_o, ga_o, psiT_o, _ = oracle_c.update_forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], X, mask=mask)
+    assert np.array_equal(eps_new[0], p["eps"][0]) and _rel(eps_new, eps_o) < TOL_PULSE and np.max(np.abs(psiT1 - psiT_o)) < 1e-10
+    # per-trajectory generators: three generators over 11 trajectories (tiles never mix generators)
+    G, K, N, NT, L = 3, 11, 64, 6, 2
+    base = wl.dense_problem(N, NT, K, L, 212, 0.05, 0.5)
+    tg = np.array([0, 1, 2, 0, 1, 2, 2, 2, 0, 0, 0], np.int32)
+    H0 = np.array([base["H0"] * (1.0 + 0.1 * g) for g in range(G)])
+    Hc = np.array([[base["Hc"][l] * (1.0 - 0.05 * g) for l in range(L)] for g in range(G)])
+    with kr.HipEngine(H0, Hc, base["tlist"], K, traj_generator=tg) as eng:
+        assert eng.info()["threads"] == 256
+        eng.set_initial_states(base["psi0"])
+        psiT = eng.forward(base["eps"])
+        _, _, chiT = wl.chi_and_JT("ss", psiT, base["tgt"])
+        eps_new, ga, psiT1 = eng.iteration(base["eps"], chiT, base["S"], base["lam"])
+    import krotov_oracle as o
+    X = [o.backward(H0[tg[k]], Hc[tg[k]], base["tlist"], base["eps"], chiT[k:k + 1])[:, 0] for k in range(K)]
+    psi, eps_o = base["psi0"].copy(), base["eps"].copy()
+    for n in range(NT):
+        du = np.array([sum(np.vdot(X[k][n], Hc[tg[k], l] @ psi[k]).imag for k in range(K)) for l in range(L)])
+        eps_o[:, n] = base["eps"][:, n] + base["S"][:, n] / base["lam"] * du
+        for k in range(K):
+            psi[k] = o.step_propagator(H0[tg[k]], Hc[tg[k]], eps_o[:, n], base["tlist"][n + 1] - base["tlist"][n]) @ psi[k]
+    assert _rel(eps_new, eps_o) < TOL_PULSE and np.max(np.abs(psiT1 - psi)) < 1e-10
