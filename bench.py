@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3")
+    ap.add_argument("--config", default="C3", help="C2 | C3 (headline, default) | C4 | C5 (workloads.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traj", type=int, default=0, help="(testing) override the trajectories per GPU of the config")
     return ap.parse_args()
@@ -71,6 +71,12 @@ def cpu_baseline(p, log):
         t_it = time.perf_counter() - t0
         out[name] = {"value": 2.0 * Ks * NTs / t_it, "iter_s": t_it, "cores": nt_, "K": Ks, "NT": NTs}
         log("cpu %s: %.3f s/iter on sample K=%d NT=%d (fw %.2fs)" % (name, t_it, Ks, NTs, t_fw))
+    # "optimised CPU": one LAPACK/Pade expm (scipy.linalg.expm) per step + OpenBLAS ZGEMM over all trajectories, NumPy's
+    # thread pool; the update integrand as one batched ZGEMM + einsum (not the reference's serial k loop)
+    try:
+        out["blas_zgemm_expm_allcores"] = cpu_blas_variant(p, min(256, K_all), min(100 if N >= 64 else 500, NT_all), log)
+    except Exception as exc:  # noqa: BLE001 -- the BLAS variant is a courtesy figure
+        log("cpu blas variant failed: %r" % (exc,))
     Ks, NTs = out["reference_order_1thread"]["K"], out["reference_order_1thread"]["NT"]
     base = out["reference_order_1thread"]
     return {"value": base["value"], "unit": "state*timesteps/s", "cores": 1, "kind": "port",
@@ -79,6 +85,41 @@ def cpu_baseline(p, log):
                       % (Ks, p["psi0"].shape[0], NTs, len(p["tlist"]) - 1),
             "variants": {k: {"value": v["value"], "cores": v["cores"], "sample_K": v["K"], "sample_NT": v["NT"]}
                          for k, v in out.items()}}
+
+
+def cpu_blas_variant(p, Ks, NTs, log):
+    """One Krotov iteration with BLAS/LAPACK doing the arithmetic (what a tuned CPU code would run): shared step
+    propagator from scipy.linalg.expm, states advanced by one ZGEMM per step, update integrand by ZGEMM + einsum."""
+    from scipy.linalg import expm
+    H0, Hc = p["H0"], p["Hc"]
+    L = Hc.shape[0]
+    tl = p["tlist"][:NTs + 1]
+    eps, S, lam = p["eps"][:, :NTs], p["S"][:, :NTs], p["lam"]
+    psi0, tgt = p["psi0"][:Ks], p["tgt"][:Ks]
+
+    def gen(e):
+        return H0 + np.tensordot(e, Hc, axes=(0, 0))
+    psi = psi0.copy()
+    for n in range(NTs):
+        psi = psi @ expm(-1j * gen(eps[:, n]) * (tl[n + 1] - tl[n])).T
+    tau = np.einsum("kn,kn->k", np.conj(tgt), psi)
+    chi = (tau / Ks)[:, None] * tgt
+    t0 = time.perf_counter()
+    X = np.empty((NTs + 1, Ks, H0.shape[0]), complex)
+    X[NTs] = chi
+    for n in range(NTs - 1, -1, -1):
+        chi = chi @ expm(-1j * gen(eps[:, n]).conj().T * (-(tl[n + 1] - tl[n]))).T
+        X[n] = chi
+    psi = psi0.copy()
+    e_new = eps.copy()
+    for n in range(NTs):
+        for l in range(L):
+            du = np.einsum("kn,kn->", np.conj(X[n]), psi @ Hc[l].T).imag
+            e_new[l, n] = eps[l, n] + S[l, n] / lam[l] * du
+        psi = psi @ expm(-1j * gen(e_new[:, n]) * (tl[n + 1] - tl[n])).T
+    t_it = time.perf_counter() - t0
+    log("cpu blas_zgemm_expm_allcores: %.3f s/iter on sample K=%d NT=%d" % (t_it, Ks, NTs))
+    return {"value": 2.0 * Ks * NTs / t_it, "iter_s": t_it, "cores": os.cpu_count() or 1, "K": Ks, "NT": NTs}
 
 
 def main():
@@ -215,15 +256,22 @@ def main():
         # command; bench.py itself does not run under rocprofv3).  Only quoted for the configuration it was taken on.
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                tj = json.load(f)
-            if tj.get("config") == args.config and world == 1:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj["source"]
+            for name in ("r02_traffic.json", "r01_traffic.json"):
+                path = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(path):
+                    continue
+                with open(path) as f:
+                    tj = json.load(f)
+                if tj.get("config") == args.config and world == 1:
+                    traffic, traffic_src = tj["traffic_bytes_per_launch"], tj["source"]
+                    break
         except (OSError, ValueError, KeyError):
             pass
         bytes_upd = K_local * NT * 32.0 * N
+        mfma_sweep = bool(info.get("matrix_core_sweep", 0))
+        kernel_name = "kr_mf_update" if mfma_sweep else ("kr_rowsplit_sweep" if info.get("rowsplit_R", 0) else "kr_sweep_update")
         line = {
-            "metric": "Krotov iters/sec + state*timesteps/sec, N=64 nt=1000 K=256 traj",
+            "metric": "Krotov iters/sec + state*timesteps/sec, N=%d nt=%d K=%d traj" % (N, NT, K_local * world),
             "value": value,
             "unit": "state*timesteps/s",
             "iters_per_sec": args.steps / elapsed,
@@ -236,25 +284,32 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s: N=%d dense Hermitian H0 + %d controls, N_T=%d, K=%d trajectories per GPU "
+            "config": {"workload": "%s (%s): N=%d %s generator + %d control operator(s), N_T=%d, K=%d trajectories per GPU "
                                    "(K_global=%d), J_T_%s, lambda_a=%g; one Krotov iteration per step"
-                                   % (args.config, N, L, NT, K_local, K_global, p["functional"], p["lam"][0]),
+                                   % (args.config, p["name"], N,
+                                      "dense Hermitian" if np.allclose(p["H0"], p["H0"].conj().T) else "dense non-Hermitian (Liouvillian)",
+                                      L, NT, K_local, K_global, p["functional"], p["lam"][0]),
                        "parallelism": parallelism,
                        "engine": info},
-            "roofline": {"bound": "mfma", "kernel": "kr_sweep_update", "achieved": achieved,
+            # bound names the unit the dominant kernel computes on: "mfma" = fp64 matrix cores (v_mfma_f64_4x4x4_4b_f64),
+            # "valu_fp64" = fp64 vector FMAs; both have the same 78.6 TFLOP/s peak on MI355X.  What BINDS is latency.
+            "roofline": {"bound": "mfma" if mfma_sweep else "valu_fp64", "binding_limit": "latency (N_T dependent steps)",
+                         "kernel": kernel_name, "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
+                         "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE); a PROFILE figure read from the "
+                                         "committed rocprofv3 --pmc summary of this command, not measured by this run",
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_upd,
                          "hbm_achieved_GBs": bytes_upd / (avg_upd * 1e-3) / 1e9 if upd_n else None, "hbm_peak_GBs": HBM_PEAK_GBS,
                          "avg_launch_ms": avg_upd, "launches": upd_n,
                          "algorithmic_flops_per_launch": flops_upd,
                          "backward_kernel": {"avg_launch_ms": avg_bw, "launches": bw_n,
                                              "achieved": (flops_bw / (avg_bw * 1e-3) / 1e12) if bw_n else None},
-                         "note": "fp64 VALU kernel (fp64 matrix peak = vector peak on MI355X); achieved counts ALGORITHMIC flops "
-                                 "(precomputed-propagator model, SURVEY 8d); the binding limit is sequential latency: N_T "
-                                 "dependent steps, each = (1+L) matvecs + one all-to-all sum over 256 workgroups + (m-1) "
-                                 "Taylor matvec rounds (m ~ 8)"},
+                         "note": "fp64 matrix peak = vector peak on MI355X; achieved counts ALGORITHMIC flops (precomputed-"
+                                 "propagator model, SURVEY 8d); the binding limit is sequential latency: N_T dependent "
+                                 "steps, each = (1+L) products + one all-to-all sum over the workgroups + (m-1) Taylor "
+                                 "rounds (m ~ 8)"},
             "J_T": {"before": float(J0), "after": float(J1)},
         }
         if not args.no_cpu_baseline and world == 1:

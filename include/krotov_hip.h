@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 1
+#define KR_ABI_VERSION 2   /* v2: kr_config grew (exchange, prop_method, device list, max_workgroups) */
 
 enum kr_status {
     KR_OK = 0,
@@ -68,6 +68,23 @@ enum kr_functional { /* standard final-time functionals, weights 1 [QuantumContr
 
 enum kr_which_storage { KR_STORAGE_FW = 0, KR_STORAGE_BW = 1 };
 
+/* How the per-step sum of the L update integrands (optimize.jl:339-349) crosses GPUs / ranks.                */
+enum kr_exchange {
+    KR_EXCHANGE_AUTO = 0,     /* mailboxes where the persistent kernels can run, else RCCL                     */
+    KR_EXCHANGE_MAILBOX = 1,  /* in-kernel peer mailboxes over xGMI (one launch per sweep)                     */
+    KR_EXCHANGE_RCCL = 2,     /* ncclAllReduce per time step between per-step kernels (the baseline BASELINE.json
+                                 names; also the fallback when mailboxes cannot be wired)                     */
+    KR_EXCHANGE_CALLBACK = 3  /* a host function sums the L doubles per step (MPI, gloo, ...)                  */
+};
+
+/* Step propagator of the sweeps (the reference's prop_method, optimize.jl:108,137-153).                      */
+enum kr_prop_method {
+    KR_PROP_AUTO = 0,    /* Taylor in the update sweep, batched exact propagators in the known-pulse sweeps    */
+    KR_PROP_TAYLOR = 1,
+    KR_PROP_CHEBY = 2,   /* Chebyshev expansion; Hermitian generators only                                     */
+    KR_PROP_NEWTON = 3   /* Newton interpolation at Leja points on the spectral bounding box                   */
+};
+
 typedef struct kr_config {
     int32_t abi_version; /* = KR_ABI_VERSION */
     int32_t N;           /* state-vector length (Hilbert or Liouville dimension)              */
@@ -87,6 +104,14 @@ typedef struct kr_config {
     int32_t rank;                  /* 0 .. world-1 */
     int32_t world;                 /* 1 = single GPU */
     int32_t K_global;              /* total trajectories over all ranks (0 -> K)               */
+    /* --- ABI v2 --- */
+    int32_t exchange;              /* kr_exchange                                              */
+    int32_t prop_method;           /* kr_prop_method                                           */
+    int32_t max_workgroups;        /* cap on co-resident persistent workgroups of this handle (0 = derive from the
+                                      device's occupancy; several handles sharing one GPU must split its CUs)   */
+    int32_t n_devices;             /* > 1: ONE handle drives n_devices GPUs from this process (trajectories block-
+                                      partitioned over them; rank/world must be 0/1); 0 or 1: `device` alone     */
+    int32_t devices[8];            /* HIP device ordinals of the n_devices GPUs (the same ordinal may repeat)     */
     int32_t reserved[8];
 } kr_config;
 
@@ -137,7 +162,8 @@ int kr_read_storage(kr_handle *h, int which, int k, int n, double *out /* [N] */
 /* Introspection for bench / tests.  info_out (16 ints): {NP, n_workgroups, traj_per_wg, threads,
  * KT, LMAX variant, K padded, store_fw, JQ, precomputed propagators, row-split R, exchange poll delay
  * (units of 128 cycles, -1 = classic schedule; measured once by kr_create),
- * Hermitian-controls kernel variant in use, 0...}.
+ * Hermitian-controls kernel variant in use, matrix-core update sweep, generic (multi-pass) known sweeps, generic / stepped
+ * update sweep, exchange in use (kr_exchange), 0}.
  * kr_enable_timing(h, 1) starts a window in which every sweep-kernel launch is bracketed by HIP
  * events on the handle's stream; kr_get_timings syncs the stream and returns, per kind
  * {forward, backward, update}: {sum of kernel durations in ms, number of launches} (6 doubles). */
@@ -148,6 +174,17 @@ int kr_enable_timing(kr_handle *h, int on);
  * update sweep per phase {matvec+dot, exchange, Taylor, store} and the sweep's length in 100 MHz
  * ticks; out: 8 x uint64.  Zero when stamps are off.                                              */
 int kr_debug_stamps(kr_handle *h, unsigned long long *out);
+
+/* Per-step exchange through RCCL (KR_EXCHANGE_RCCL): rank 0 makes a unique id, the host side broadcasts it, every
+ * rank calls kr_rccl_init (collective).  librccl is loaded at run time (dlopen): no link-time dependency.
+ * A handle with a device list (n_devices > 1) sets its communicators up by itself.                              */
+int kr_rccl_unique_id_size(void);
+int kr_rccl_get_unique_id(void *id_out /* kr_rccl_unique_id_size() bytes */);
+int kr_rccl_init(kr_handle *h, const void *unique_id);
+/* Per-step exchange through a host function (KR_EXCHANGE_CALLBACK): fn must sum buf[0..count-1] over all ranks in place
+ * (the same result on every rank) and return 0; it is called once per time step from the calling thread.        */
+typedef int (*kr_allreduce_fn)(void *ctx, double *buf, int count);
+int kr_set_exchange_callback(kr_handle *h, kr_allreduce_fn fn, void *ctx);
 
 /* Multi-GPU mailbox wiring (in-kernel per-step exchange of the L partial sums).
  * Each rank exports an IPC handle of its mailbox, the host side all-gathers them

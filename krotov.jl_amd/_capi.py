@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KROTOV_HIP_LIB", os.path.join(_HERE, "lib", "libkrotov_hip.so"))  # env: A/B builds
 
-KR_ABI_VERSION = 1
+KR_ABI_VERSION = 2
 KR_OK, KR_ERR_INVALID, KR_ERR_NO_DEVICE, KR_ERR_HIP, KR_ERR_UNSUPPORTED, KR_ERR_TIMEOUT, KR_ERR_STATE = range(7)
 KR_STORE_FW, KR_NO_STORE_FW = 1, 2
 KR_J_T_SM, KR_J_T_SS, KR_J_T_RE = 0, 1, 2
@@ -25,7 +25,11 @@ EXPORTS = [
     "kr_iteration_functional_dev", "kr_final_states", "kr_taus", "kr_g_a_int", "kr_synchronize",
     "kr_read_storage", "kr_get_info", "kr_get_timings", "kr_enable_timing", "kr_debug_stamps",
     "kr_ipc_handle_size", "kr_ipc_export", "kr_ipc_connect",
+    "kr_rccl_unique_id_size", "kr_rccl_get_unique_id", "kr_rccl_init", "kr_set_exchange_callback",
 ]
+KR_EXCHANGE_AUTO, KR_EXCHANGE_MAILBOX, KR_EXCHANGE_RCCL, KR_EXCHANGE_CALLBACK = range(4)
+KR_PROP_AUTO, KR_PROP_TAYLOR, KR_PROP_CHEBY, KR_PROP_NEWTON = range(4)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 
 class KrConfig(C.Structure):
@@ -36,6 +40,8 @@ class KrConfig(C.Structure):
         ("hc_present", C.c_void_p),
         ("flags", C.c_uint32), ("prop_tol", C.c_double), ("device", C.c_int32),
         ("rank", C.c_int32), ("world", C.c_int32), ("K_global", C.c_int32),
+        ("exchange", C.c_int32), ("prop_method", C.c_int32), ("max_workgroups", C.c_int32),
+        ("n_devices", C.c_int32), ("devices", C.c_int32 * 8),
         ("reserved", C.c_int32 * 8),
     ]
 
@@ -65,9 +71,14 @@ def _share_hip_runtime_with_torch():
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.submodule_search_locations:
             return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        cand = os.path.join(libdir, "libamdhip64.so")
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        # the same for RCCL, but only by NAME: libkrotov_hip dlopens it when (and only when) exchange = RCCL is used
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("KROTOV_HIP_RCCL_LIB", rccl)
     except Exception:  # noqa: BLE001 -- fall back to the system runtime
         pass
 

@@ -142,3 +142,31 @@ static inline hipError_t kr_launch_mf64(int lmax, int tiles, int kind, int grid,
 // row-split kernels (kr_device_rowsplit.h): second argument = rows per workgroup
 hipError_t kr_launch_rs128(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_rs256(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+
+// generic (multi-pass) kernels (kr_device_generic.h)
+struct KrGenArgs {
+    const double2 *H;          // [G][1 + L][N * N] column-major (forward pack, or the adjoint pack for dir = -1)
+    size_t gen_stride;         // elements between two generators
+    double2 *Heps;             // [G][N * N] scratch: H(eps) of the current step (update sweep)
+    const int *tile_gen;       // [tiles] generator of each tile (nullptr: all 0)
+    const double *nrm;         // [G][1 + L] 2-norm bounds
+    const unsigned *present;   // [G] presence bits (L <= 32)
+    const double *eps;         // [L][NT] pulses of this sweep (known) / guess pulses (update)
+    const double *alpha;       // [L][NT]
+    double *eps_new;           // [L][NT]
+    double *g_a_int;           // [L] running integrals (device)
+    const double *dt;          // [NT]
+    const double2 *init;       // [Kp][N]
+    double2 *state;            // [Kp][N] running state of the update sweep
+    double2 *store;            // [(NT+1)][Kp][N] or nullptr
+    double2 *fin;              // [Kp][N] or nullptr
+    const double2 *X;          // [(NT+1)][Kp][N]
+    double *partial;           // [tiles][L]
+    double *du_local;          // [L]
+    const double *du_total;    // [L]
+    double tol;
+    double thr[KR_MAX_ORDER];
+    int N, NT, Kp, L, G, KTG, RP, JQ, tiles, dir, n;
+};
+
+hipError_t kr_launch_generic(int kind, int ktg, int grid, size_t lds_bytes, hipStream_t s, const KrGenArgs *a);

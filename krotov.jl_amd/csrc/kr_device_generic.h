@@ -1,0 +1,240 @@
+// Generic sweep kernels: any state dimension N, any number of controls L, any number of trajectories K, and NO
+// co-residency requirement -- ordinary grids, one launch per sweep (known pulses) or a few launches per time step (update
+// sweep).  They are
+//   * the multi-pass path behind the capacity limits of the persistent kernels (N > 256, L > 4, more trajectories than
+//     co-resident workgroups can carry, or a device on which the persistent grid cannot be resident at once), and
+//   * the carrier of the per-step exchanges that cannot run inside a kernel: the RCCL all-reduce of the L partial sums
+//     that BASELINE.json's north_star names as the multi-GPU baseline, and a host callback (MPI, gloo, ...).
+// Update sweep, per step n (/root/reference/src/optimize.jl:328-370):
+//     kr_gen_partial   partial[tile][l] = sum_{k in tile} Im<chi_k(t_n)|H_l|psi_k(t_n)>            (:339-349)
+//     kr_gen_reduce    du_local[l] = sum_tiles partial (fixed order)
+//     [exchange]       du_total = sum over ranks (ncclAllReduce on the stream / host callback / none)
+//     kr_gen_form      eps_new[l][n] = eps[l][n] + alpha du, g_a_int += ...; Heps = H0 + sum eps_new_l H_l (:351-358)
+//     kr_gen_apply     psi_k <- exp(-i Heps dt) psi_k (Taylor/Horner, same plan as the persistent kernels)  (:360-368)
+// Operators are read column-major exactly as the caller (Julia) hands them over: thread i owns row i, so the loads of a
+// column are coalesced; the adjoint pack (backward sweep, workspace.jl:69) is a second column-major copy of H^dagger.
+// A workgroup of 256 threads carries KTG trajectories (each operator element is loaded once for all of them); with N < 256
+// the JQ = 256 / RP thread groups split the columns and their partial row sums meet in LDS in a fixed order.
+#pragma once
+#include "kr_common.h"
+
+__device__ __forceinline__ void kr_gen_plan(const KrGenArgs &a, const double theta, int &s, int &m) {
+    if (theta <= KR_THETA_MAX) {
+        s = 1;
+        m = 1;
+        while (m < KR_MAX_ORDER - 1 && theta > a.thr[m]) ++m;   // thr is increasing in m: same plan as kr_plan_fast
+    } else {
+        kr_taylor_plan(theta, a.tol, s, m);
+    }
+}
+
+// out[q][i] = sum_j (sum_m c_m M_m[i][j]) x[q][j] for the rows i = this thread's row (+ RP, ...), all KTG states q.
+// NMAT matrices M_m (consecutive N*N blocks at Hb) with real coefficients c_m; x and out are LDS vectors [KTG][N];
+// red: LDS scratch [JQ][KTG][RP].  All threads call it; ends with a barrier.
+template <int KTG>
+__device__ __forceinline__ void kr_gen_matvec(const KrGenArgs &a, const double2 *__restrict__ Hb, const int nmat, const double *c,
+                                              const double2 *x, double2 *out, double2 *red) {
+    const int N = a.N, RP = a.RP, JQ = a.JQ, tid = threadIdx.x;
+    const int i0 = tid % RP, jq = tid / RP;
+    const size_t nn = (size_t)N * N;
+    for (int ib = 0; ib < N; ib += RP) {
+        const int i = ib + i0;
+        double sr[KTG], si[KTG];
+#pragma unroll
+        for (int q = 0; q < KTG; ++q) { sr[q] = 0.0; si[q] = 0.0; }
+        if (i < N && jq < JQ) {
+            for (int j = jq; j < N; j += JQ) {
+                double hr = 0.0, hi = 0.0;
+                for (int mm = 0; mm < nmat; ++mm) {
+                    const double2 h = Hb[(size_t)mm * nn + i + (size_t)j * N];
+                    hr = fma(c[mm], h.x, hr);
+                    hi = fma(c[mm], h.y, hi);
+                }
+#pragma unroll
+                for (int q = 0; q < KTG; ++q) {
+                    const double2 xv = x[q * N + j];
+                    sr[q] = fma(hr, xv.x, fma(-hi, xv.y, sr[q]));
+                    si[q] = fma(hr, xv.y, fma(hi, xv.x, si[q]));
+                }
+            }
+        }
+        if (JQ > 1) {
+            if (i0 < RP && jq < JQ) {
+#pragma unroll
+                for (int q = 0; q < KTG; ++q) red[(jq * KTG + q) * RP + i0] = make_double2(sr[q], si[q]);
+            }
+            __syncthreads();
+            if (jq == 0 && i < N) {
+#pragma unroll
+                for (int q = 0; q < KTG; ++q) {
+                    double tr = 0.0, ti = 0.0;
+                    for (int g = 0; g < JQ; ++g) { const double2 v = red[(g * KTG + q) * RP + i0]; tr += v.x; ti += v.y; }
+                    out[q * N + i] = make_double2(tr, ti);
+                }
+            }
+            __syncthreads();
+        } else if (i < N) {
+#pragma unroll
+            for (int q = 0; q < KTG; ++q) out[q * N + i] = make_double2(sr[q], si[q]);
+        }
+    }
+    __syncthreads();
+}
+
+// psi (LDS, [KTG][N]) <- exp(-i sdt sum_m c_m M_m) psi by Horner/Taylor with sub-stepping; y0, y1: LDS scratch vectors
+template <int KTG>
+__device__ __forceinline__ void kr_gen_propagate(const KrGenArgs &a, const double2 *Hb, const int nmat, const double *c,
+                                                 const double theta, const double sdt, double2 *psi, double2 *y0, double2 *y1,
+                                                 double2 *red) {
+    int s, m;
+    kr_gen_plan(a, theta, s, m);
+    const double fs = (s == 1) ? sdt : sdt / (double)s;
+    const int tot = KTG * a.N;
+    for (int sub = 0; sub < s; ++sub) {
+        const double2 *src = psi;
+        double2 *dst = y0;
+        for (int j = m; j >= 1; --j) {   // y <- psi + (-i fs / j) H y
+            kr_gen_matvec<KTG>(a, Hb, nmat, c, src, y1, red);
+            const double f = fs * kr_rinv[j];
+            double2 *target = (j == 1) ? y0 : dst;
+            for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+                const double2 hv = y1[e], p = psi[e];
+                target[e] = make_double2(fma(f, hv.y, p.x), fma(-f, hv.x, p.y));
+            }
+            __syncthreads();
+            src = target;
+        }
+        for (int e = threadIdx.x; e < tot; e += blockDim.x) psi[e] = y0[e];
+        __syncthreads();
+    }
+}
+
+#define KR_GEN_LDS(KTG) \
+    extern __shared__ __attribute__((aligned(16))) double2 kr_gen_lds[]; \
+    double2 *psi = kr_gen_lds, *y0 = psi + (KTG) * a.N, *y1 = y0 + (KTG) * a.N, *red = y1 + (KTG) * a.N;
+
+// known-pulse sweep, one launch: every workgroup runs its tile through all N_T steps (no inter-workgroup dependency)
+template <int KTG>
+__global__ __launch_bounds__(256) void kr_gen_known(const KrGenArgs a) {
+    KR_GEN_LDS(KTG)
+    const int tile = blockIdx.x, N = a.N, NT = a.NT, L = a.L, tot = KTG * N;
+    const int gen = a.tile_gen ? a.tile_gen[tile] : 0;
+    const double2 *Hb = a.H + (size_t)gen * a.gen_stride;
+    const size_t tb = (size_t)tile * KTG * N, slab = (size_t)a.Kp * N;
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+        const double2 v = a.init[tb + e];
+        psi[e] = v;
+        if (a.store) a.store[(size_t)((a.dir > 0) ? 0 : NT) * slab + tb + e] = v;
+    }
+    __syncthreads();
+    double c[1 + 32];
+    for (int step = 0; step < NT; ++step) {
+        const int n = (a.dir > 0) ? step : (NT - 1 - step);
+        const double sdt = (a.dir > 0) ? a.dt[n] : -a.dt[n];
+        double theta = a.nrm[(size_t)gen * (1 + L)];
+        c[0] = 1.0;
+        for (int l = 0; l < L; ++l) { c[1 + l] = a.eps[(size_t)l * NT + n]; theta += fabs(c[1 + l]) * a.nrm[(size_t)gen * (1 + L) + 1 + l]; }
+        kr_gen_propagate<KTG>(a, Hb, 1 + L, c, theta * fabs(sdt), sdt, psi, y0, y1, red);
+        if (a.store) {
+            const int slot = (a.dir > 0) ? (n + 1) : n;
+            for (int e = threadIdx.x; e < tot; e += blockDim.x) a.store[(size_t)slot * slab + tb + e] = psi[e];
+        }
+    }
+    if (a.fin) for (int e = threadIdx.x; e < tot; e += blockDim.x) a.fin[tb + e] = psi[e];
+}
+
+// update sweep, step a.n: partial sums of the update integrand over this tile's trajectories
+template <int KTG>
+__global__ __launch_bounds__(256) void kr_gen_partial(const KrGenArgs a) {
+    KR_GEN_LDS(KTG)
+    __shared__ double sred[256];
+    const int tile = blockIdx.x, N = a.N, L = a.L, tot = KTG * N;
+    const int gen = a.tile_gen ? a.tile_gen[tile] : 0;
+    const size_t tb = (size_t)tile * KTG * N, slab = (size_t)a.Kp * N;
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+        psi[e] = a.state[tb + e];
+        y0[e] = a.X[(size_t)a.n * slab + tb + e];   // chi(t_n)
+    }
+    __syncthreads();
+    const double one = 1.0;
+    for (int l = 0; l < L; ++l) {
+        double acc = 0.0;
+        if ((a.present[gen] >> l) & 1u) {
+            kr_gen_matvec<KTG>(a, a.H + (size_t)gen * a.gen_stride + (size_t)(1 + l) * N * N, 1, &one, psi, y1, red);
+            for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+                const double2 ch = y0[e], av = y1[e];
+                acc += ch.x * av.y - ch.y * av.x;   // Im(conj(chi) a)
+            }
+        }
+        sred[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {   // fixed tree: bitwise reproducible
+            if ((int)threadIdx.x < o) sred[threadIdx.x] += sred[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.partial[(size_t)tile * L + l] = sred[0];
+        __syncthreads();
+    }
+}
+
+// du_local[l] = sum over tiles, fixed order (one workgroup)
+__global__ __launch_bounds__(256) void kr_gen_reduce(const KrGenArgs a) {
+    __shared__ double sred[256];
+    for (int l = 0; l < a.L; ++l) {
+        double acc = 0.0;
+        for (int t = threadIdx.x; t < a.tiles; t += 256) acc += a.partial[(size_t)t * a.L + l];
+        sred[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sred[threadIdx.x] += sred[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.du_local[l] = sred[0];
+        __syncthreads();
+    }
+}
+
+// pulse update of step a.n (identical on every rank: du_total is) and H(eps_new) for every generator
+__global__ __launch_bounds__(256) void kr_gen_form(const KrGenArgs a) {
+    const int N = a.N, NT = a.NT, L = a.L, n = a.n;
+    const size_t nn = (size_t)N * N, idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nn * a.G) return;
+    const int gen = (int)(idx / nn);
+    const size_t e = idx % nn;
+    const double2 *Hb = a.H + (size_t)gen * a.gen_stride;
+    double2 h = Hb[e];
+    for (int l = 0; l < L; ++l) {
+        const double al = a.alpha[(size_t)l * NT + n], eg = a.eps[(size_t)l * NT + n], du = a.du_total[l];
+        const double en = __dadd_rn(eg, __dmul_rn(al, du));   // optimize.jl:355, no FMA contraction
+        const double2 hl = Hb[(size_t)(1 + l) * nn + e];
+        h.x = fma(en, hl.x, h.x);
+        h.y = fma(en, hl.y, h.y);
+        if (idx == 0) {
+            a.eps_new[(size_t)l * NT + n] = en;
+            const double ad = fabs(du);
+            a.g_a_int[l] = __dadd_rn(a.g_a_int[l], __dmul_rn(__dmul_rn(al, __dmul_rn(ad, ad)), a.dt[n]));   // optimize.jl:356
+        }
+    }
+    a.Heps[(size_t)gen * nn + e] = h;
+}
+
+// forward step of the update sweep under the new pulse
+template <int KTG>
+__global__ __launch_bounds__(256) void kr_gen_apply(const KrGenArgs a) {
+    KR_GEN_LDS(KTG)
+    const int tile = blockIdx.x, N = a.N, NT = a.NT, L = a.L, n = a.n, tot = KTG * N;
+    const int gen = a.tile_gen ? a.tile_gen[tile] : 0;
+    const size_t tb = (size_t)tile * KTG * N, slab = (size_t)a.Kp * N;
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) psi[e] = a.state[tb + e];
+    __syncthreads();
+    double theta = a.nrm[(size_t)gen * (1 + L)];
+    for (int l = 0; l < L; ++l) theta += fabs(a.eps_new[(size_t)l * NT + n]) * a.nrm[(size_t)gen * (1 + L) + 1 + l];
+    const double one = 1.0, dtn = a.dt[n];
+    kr_gen_propagate<KTG>(a, a.Heps + (size_t)gen * N * N, 1, &one, theta * fabs(dtn), dtn, psi, y0, y1, red);
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+        a.state[tb + e] = psi[e];
+        if (a.store) a.store[(size_t)(n + 1) * slab + tb + e] = psi[e];
+        if (a.fin && n == NT - 1) a.fin[tb + e] = psi[e];
+    }
+}
+#undef KR_GEN_LDS

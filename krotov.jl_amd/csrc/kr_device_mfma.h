@@ -127,7 +127,9 @@ __device__ __forceinline__ void kr_mf_put(double2 *W, const int doff, const int 
     ((double *)W)[2 * zoff] = zs * yv;
 }
 
-template <int LMAX, int TILES, int SCHED, int HERM>
+// CAL = 1: the same kernel under another name for the short sweeps of calibrate_exchange (krotov_hip.hip), so that profiler
+// statistics of kr_mf_update<..., 0> hold the caller's launches only.
+template <int LMAX, int TILES, int SCHED, int HERM, int CAL>
 __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     constexpr int KT = 2 * TILES, TW = KR_MF_TW, NW = 4;
     constexpr int CH = KT;  // 16-B elements per lane when the memory wave moves a whole tile (KT * 64 / 64)
@@ -433,24 +435,30 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     }
 }
 
-// kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (as kr_launch_np; the CAL bit is ignored: calibration launches run the same
-// kernel); tiles = trajectories per workgroup / 2.  One translation unit per LMAX (kr_mf64_l2.hip, kr_mf64_l4.hip).
+// kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (as kr_launch_np); tiles = trajectories per workgroup / 2.
+// One translation unit per LMAX (kr_mf64_l2.hip, kr_mf64_l4.hip).
 template <int LM>
 static hipError_t kr_launch_mfma64(int tiles, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
     if ((kind & 15) != 1) return hipErrorInvalidValue;
-    const int sched = (kind >> 4) & 1, herm = (kind >> 6) & 1;
+    const int v = ((kind >> 4) & 1) | (((kind >> 6) & 1) << 1) | (((kind >> 5) & 1) << 2);   // SCHED | HERM << 1 | CAL << 2
 #define KR_CASE_M(TL)                                                                                              \
     if (tiles == TL) {                                                                                             \
-        if (!sched && !herm) hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 0>), dim3(grid), dim3(256), 0, s, *a);    \
-        else if (sched && !herm) hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 0>), dim3(grid), dim3(256), 0, s, *a); \
-        else if (!sched && herm) hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 1>), dim3(grid), dim3(256), 0, s, *a); \
-        else hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 1>), dim3(grid), dim3(256), 0, s, *a);                    \
+        switch (v) {                                                                                               \
+        case 0: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 0, 0>), dim3(grid), dim3(256), 0, s, *a); break;       \
+        case 1: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 0, 0>), dim3(grid), dim3(256), 0, s, *a); break;       \
+        case 2: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 1, 0>), dim3(grid), dim3(256), 0, s, *a); break;       \
+        case 3: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 1, 0>), dim3(grid), dim3(256), 0, s, *a); break;       \
+        case 4: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 0, 1>), dim3(grid), dim3(256), 0, s, *a); break;       \
+        case 5: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 0, 1>), dim3(grid), dim3(256), 0, s, *a); break;       \
+        case 6: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 1, 1>), dim3(grid), dim3(256), 0, s, *a); break;       \
+        default: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 1, 1>), dim3(grid), dim3(256), 0, s, *a); break;      \
+        }                                                                                                          \
         return hipGetLastError();                                                                                  \
     }
 #ifdef KR_MF_ONLY_TILES
     KR_CASE_M(KR_MF_ONLY_TILES)
 #else
-    KR_CASE_M(1) KR_CASE_M(2)   // (4 tiles: the six vector arrays + H0 exceed the CU's LDS and the accumulators spill)
+    KR_CASE_M(1) KR_CASE_M(2)   // (4 tiles: the vector arrays + H0 exceed the CU's LDS and the accumulators spill)
 #endif
 #undef KR_CASE_M
     return hipErrorInvalidValue;

@@ -10,6 +10,8 @@
 // adjoint) is built here once per handle for all K trajectories.
 #include "../../include/krotov_hip.h"
 #include "kr_common.h"
+#include <rccl/rccl.h>   // types only: librccl is loaded with dlopen (kr_rccl_*), never linked
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -77,6 +79,20 @@ struct kr_handle {
     bool debug_on = false;
     unsigned epoch_base = 0;
     bool have_psi0 = false, have_tgt = false, have_X = false, have_final = false, have_params = false;
+    // generic (multi-pass) path, kr_device_generic.h: known-pulse sweeps / update sweep run there when the persistent
+    // kernels cannot (capacity) or must not (per-step RCCL / callback exchange)
+    bool fast_ok = true;       // the persistent kernels have a plan for this problem
+    bool gen_known = false, gen_update = false;
+    int KTG = 0, RP = 0, JQg = 0, gen_tiles = 0;
+    size_t gen_lds = 0, col_stride = 0;
+    double2 *Hcol_fw = nullptr, *Hcol_bw = nullptr, *Heps_d = nullptr;
+    int *tile_gen_d = nullptr;
+    double *nrm_gen_d = nullptr, *partial_d = nullptr, *du_local_d = nullptr, *du_total_d = nullptr;
+    double *du_host = nullptr;   // pinned, callback exchange
+    int exchange = KR_EXCHANGE_AUTO;   // resolved at kr_create
+    kr_allreduce_fn cb = nullptr;
+    void *cb_ctx = nullptr;
+    ncclComm_t rccl_comm = nullptr;
     // timing: per kind (0 forward, 1 backward, 2 update) a pool of event pairs, one per launch since
     // the last reset; durations are read back (after a stream sync) by kr_get_timings
     bool timing = false;
@@ -222,8 +238,45 @@ __global__ void kr_chi_kernel(int functional, const double2 *tgt, const double2 
     chi[idx] = c;
 }
 
+// ---- RCCL, loaded at run time ---------------------------------------------------------------------
+// The library has no link-time dependency on librccl: KR_EXCHANGE_RCCL resolves the five entry points it needs with
+// dlopen/dlsym, preferring a librccl that is already mapped into the process (PyTorch-ROCm brings its own).
+struct KrRccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+static KrRccl *kr_rccl() {
+    static KrRccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // One RCCL per process: a second copy (PyTorch-ROCm bundles its own librccl.so, which its libtorch_hip.so requests
+        // under that name) ends in a double free at exit.  KROTOV_HIP_RCCL_LIB names the copy to use (the Python binding
+        // points it at PyTorch's file); otherwise whatever is mapped already, then the system library.
+        const char *envp = getenv("KROTOV_HIP_RCCL_LIB");
+        const char *names[] = {(envp && *envp) ? envp : "librccl.so", "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char *n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) { r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+#define KR_SYM(field, name) r.field = (decltype(r.field))dlsym(r.lib, name); if (!r.field) r.why = std::string("librccl lacks ") + name;
+        KR_SYM(GetUniqueId, "ncclGetUniqueId") KR_SYM(CommInitRank, "ncclCommInitRank") KR_SYM(CommInitAll, "ncclCommInitAll")
+        KR_SYM(CommDestroy, "ncclCommDestroy") KR_SYM(AllReduce, "ncclAllReduce") KR_SYM(GroupStart, "ncclGroupStart")
+        KR_SYM(GroupEnd, "ncclGroupEnd") KR_SYM(GetErrorString, "ncclGetErrorString")
+#undef KR_SYM
+    });
+    return r.why.empty() ? &r : nullptr;
+}
+static const char *kr_rccl_why() { (void)kr_rccl(); static KrRccl *dummy = nullptr; (void)dummy; return "librccl could not be loaded (dlopen)"; }
+
 // ---- plan -------------------------------------------------------------------------------------
-static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) {
+static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen, int maxwg_cfg) {
     const kr_config &c = h->cfg;
     if (c.N > 256) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 256 is not supported by this build", c.N);
     if (c.L > KR_LMAX_CAP) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > %d controls not supported by this build", c.L, KR_LMAX_CAP);
@@ -254,7 +307,9 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
     int cus = prop.multiProcessorCount;
-    int maxwg = env_int("KROTOV_HIP_MAX_WG", cus);  // one persistent workgroup per CU
+    // one persistent workgroup per CU; a handle that shares its GPU (several ranks or shards per device) gets a share:
+    // kr_config.max_workgroups (a device list with repeated ordinals sets it by itself), or the environment for tests
+    int maxwg = env_int("KROTOV_HIP_MAX_WG", maxwg_cfg > 0 ? std::min(maxwg_cfg, cus) : cus);
     if (maxwg < 1) maxwg = 1;
     if (NP > 64 && env_int("KROTOV_HIP_ROWSPLIT", 1) != 0) {
         // R workgroups per trajectory, NR = NP / R rows each (8 <= NR <= 64: the H(eps) block must fit the registers)
@@ -335,18 +390,96 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
     return KR_OK;
 }
 
+// Generic plan (kr_device_generic.h): tiles of KTG trajectories, as many workgroups as it takes.
+static int gen_geometry(kr_handle *h, int ktile_limit) {
+    const int N = h->cfg.N;
+    int rp = 16;
+    while (rp < N && rp < 256) rp <<= 1;
+    h->RP = rp;
+    h->JQg = 256 / rp;
+    auto lds = [&](int ktg) { return ((size_t)3 * ktg * N + (size_t)h->JQg * ktg * rp) * sizeof(double2); };
+    int ktg = 4;
+    while (ktg > 1 && (lds(ktg) > 64 * 1024 || (ktile_limit > 0 && ktile_limit % ktg != 0))) ktg >>= 1;
+    if (lds(ktg) > 150 * 1024) return fail(h, KR_ERR_UNSUPPORTED, "N = %d: three state vectors do not fit the CU's LDS (generic kernels)", N);
+    h->KTG = ktg;
+    h->gen_lds = lds(ktg);
+    return KR_OK;
+}
+
+// Plan: the persistent kernels where they have one; the generic kernels for what they cannot carry (N > 256, L > 4, more
+// trajectories than co-resident workgroups) and for the update sweep whenever the per-step exchange runs outside the kernel
+// (RCCL / callback).  KROTOV_HIP_GENERIC = 1 forces the generic kernels everywhere (tests), 0 forbids the fallback.
+static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) {
+    const kr_config &c = h->cfg;
+    const int genv = env_int("KROTOV_HIP_GENERIC", -1);
+    if (c.L > 32) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > 32 controls not supported", c.L);
+    if (c.exchange < KR_EXCHANGE_AUTO || c.exchange > KR_EXCHANGE_CALLBACK) return fail(h, KR_ERR_INVALID, "kr_create: exchange = %d", c.exchange);
+    int rc = (genv == 1) ? KR_ERR_UNSUPPORTED : make_plan_fast(h, tg, wg_gen, c.max_workgroups);
+    h->fast_ok = (rc == KR_OK);
+    if (rc != KR_OK && rc != KR_ERR_UNSUPPORTED) return rc;
+    if (!h->fast_ok && genv == 0) return rc;
+    // exchange
+    int ex = c.exchange;
+    if (ex == KR_EXCHANGE_AUTO) ex = h->fast_ok ? KR_EXCHANGE_MAILBOX : (c.world > 1 ? KR_EXCHANGE_RCCL : KR_EXCHANGE_MAILBOX);
+    if (ex == KR_EXCHANGE_MAILBOX && !h->fast_ok && c.world > 1)
+        return fail(h, KR_ERR_UNSUPPORTED, "this problem runs on the generic kernels (%s); with world > 1 they need exchange = RCCL or CALLBACK", h->err.c_str());
+    h->exchange = ex;
+    h->gen_known = !h->fast_ok;
+    h->gen_update = !h->fast_ok || ex == KR_EXCHANGE_RCCL || ex == KR_EXCHANGE_CALLBACK;
+    if (!h->gen_known && !h->gen_update) return KR_OK;
+    if (h->fast_ok) {
+        // stepped update sweep on the fast plan's trajectory layout: generic tiles subdivide its tiles
+        rc = gen_geometry(h, h->KTILE);
+        if (rc) return rc;
+        h->gen_tiles = h->Kp / h->KTG;
+        return KR_OK;
+    }
+    // everything generic: own layout (generator groups one after the other, each padded to whole tiles of KTG)
+    h->err.clear();
+    h->mfma_sweep = false; h->rowsplit = false; h->herm = false;
+    rc = gen_geometry(h, 0);
+    if (rc) return rc;
+    h->NP = 0; h->LMAXv = 0; h->threads = 256; h->JQ = h->JQg; h->JS = 0; h->RT = 256; h->SG = 1;
+    h->KT = h->KTG; h->KTILE = h->KTG;
+    std::vector<int> count(h->G, 0);
+    for (int k = 0; k < c.K; ++k) count[tg ? tg[k] : 0]++;
+    int tiles = 0;
+    for (int g = 0; g < h->G; ++g) tiles += (count[g] + h->KTG - 1) / h->KTG;
+    h->P = tiles; h->gen_tiles = tiles; h->Kp = tiles * h->KTG;
+    h->perm.assign(c.K, 0);
+    wg_gen.assign(tiles, 0);
+    std::vector<int> tile_base(h->G, 0), seen(h->G, 0);
+    int t = 0;
+    for (int g = 0; g < h->G; ++g) {
+        tile_base[g] = t;
+        const int nt = (count[g] + h->KTG - 1) / h->KTG;
+        for (int q = 0; q < nt; ++q) wg_gen[t + q] = g;
+        t += nt;
+    }
+    h->identity_perm = true;
+    for (int k = 0; k < c.K; ++k) {
+        const int g = tg ? tg[k] : 0;
+        h->perm[k] = tile_base[g] * h->KTG + seen[g]++;
+        if (h->perm[k] != k) h->identity_perm = false;
+    }
+    return KR_OK;
+}
+
 extern "C" int kr_abi_version(void) { return KR_ABI_VERSION; }
 
 extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
-                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw};
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d,
+                    h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected)
         for (int r = 0; r < h->cfg.world; ++r)
             if (r != h->cfg.rank && h->peer_xmail[r]) (void)hipIpcCloseMemHandle(h->peer_xmail[r]);
     if (h->xmail_d) (void)hipFree(h->xmail_d);
+    if (h->du_host) (void)hipHostFree(h->du_host);
+    if (h->rccl_comm && kr_rccl()) (void)kr_rccl()->CommDestroy(h->rccl_comm);
     for (auto &pool : h->ev) for (auto &e : pool) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
@@ -448,19 +581,22 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     // norms, presence masks and packs, per generator
     const int G = h->G;
     const zc *H0 = (const zc *)cfg->H0, *Hc = (const zc *)cfg->Hc;
-    std::vector<double> nrm((size_t)G * (1 + KR_LMAX_CAP), 0.0);
+    std::vector<double> nrm((size_t)G * (1 + KR_LMAX_CAP), 0.0), nrm_gen((size_t)G * (1 + L), 0.0);
     std::vector<unsigned> present(G, 0u);
     h->pack_stride = (size_t)(1 + L) * NP * NP;  // = (1+L) * JS * RT in every geometry
-    const size_t pack_elems = h->pack_stride * G;
+    const size_t pack_elems = h->fast_ok ? h->pack_stride * G : 0;
     std::vector<double2> pack(pack_elems);
-    CHK(dalloc(&h->Hpack_fw, pack_elems));
-    CHK(dalloc(&h->Hpack_bw, pack_elems));
+    if (h->fast_ok) {
+        CHK(dalloc(&h->Hpack_fw, pack_elems));
+        CHK(dalloc(&h->Hpack_bw, pack_elems));
+    }
     for (int g = 0; g < G; ++g) {
-        nrm[(size_t)g * (1 + KR_LMAX_CAP)] = norm2_bound(N, H0 + (size_t)g * nn);
+        nrm_gen[(size_t)g * (1 + L)] = norm2_bound(N, H0 + (size_t)g * nn);
         for (int l = 0; l < L; ++l) {
             if (!cfg->hc_present || cfg->hc_present[(size_t)g * L + l]) present[g] |= 1u << l;
-            nrm[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l] = norm2_bound(N, Hc + ((size_t)g * L + l) * nn);
+            nrm_gen[(size_t)g * (1 + L) + 1 + l] = norm2_bound(N, Hc + ((size_t)g * L + l) * nn);
         }
+        for (int m = 0; m <= L && m <= KR_LMAX_CAP; ++m) nrm[(size_t)g * (1 + KR_LMAX_CAP) + m] = nrm_gen[(size_t)g * (1 + L) + m];
     }
     // HERM variant of the update kernel: every control operator that enters the update integrand is exactly Hermitian
     // (KROTOV_HIP_HERM: 0 = never, 1 = where it was measured to pay: one trajectory per team and >= 64 workgroups -- C3
@@ -482,7 +618,7 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
                     if (M[(size_t)c * N + r] != std::conj(M[(size_t)r * N + c])) { h->herm = false; break; }
         }
     }
-    for (int adj = 0; adj < 2; ++adj) {
+    for (int adj = 0; adj < 2 && h->fast_ok; ++adj) {
         for (int g = 0; g < G; ++g)
             for (int m = 0; m <= L; ++m)
             {
@@ -506,6 +642,43 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
         CHK(dalloc(&h->Hdense_fw, dense.size()));
         CHK(hipMemcpy(h->Hdense_fw, dense.data(), dense.size() * sizeof(double2), hipMemcpyHostToDevice));
     }
+    if (h->gen_known || h->gen_update) {
+        // generic kernels: the operators column-major as the caller hands them over (+ the adjoint, column-major), the
+        // generator of every generic tile, norms for any L, scratch for the per-step pipeline
+        h->col_stride = (size_t)(1 + L) * nn;
+        std::vector<double2> col(h->col_stride * G);
+        for (int adj = 0; adj < 2; ++adj) {
+            if (adj == 0 && !h->gen_update && !h->gen_known) continue;
+            if (adj == 1 && !h->gen_known) continue;
+            for (int g = 0; g < G; ++g)
+                for (int m = 0; m <= L; ++m) {
+                    const zc *M = (m == 0) ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn;
+                    double2 *dst = col.data() + (size_t)g * h->col_stride + (size_t)m * nn;
+                    for (int j = 0; j < N; ++j)
+                        for (int i = 0; i < N; ++i) {
+                            const zc v = adj ? std::conj(M[j + (size_t)i * N]) : M[i + (size_t)j * N];
+                            dst[i + (size_t)j * N] = make_double2(v.real(), v.imag());
+                        }
+                }
+            double2 **dstp = adj ? &h->Hcol_bw : &h->Hcol_fw;
+            CHK(dalloc(dstp, col.size()));
+            CHK(hipMemcpy(*dstp, col.data(), col.size() * sizeof(double2), hipMemcpyHostToDevice));
+        }
+        std::vector<int> tile_gen(h->gen_tiles, 0);
+        const int per = h->KTILE / h->KTG;   // generic tiles per plan tile
+        for (int t = 0; t < h->gen_tiles; ++t) tile_gen[t] = wg_gen.empty() ? 0 : wg_gen[std::min((size_t)(t / std::max(per, 1)), wg_gen.size() - 1)];
+        CHK(dalloc(&h->tile_gen_d, tile_gen.size()));
+        CHK(hipMemcpy(h->tile_gen_d, tile_gen.data(), tile_gen.size() * sizeof(int), hipMemcpyHostToDevice));
+        CHK(dalloc(&h->nrm_gen_d, nrm_gen.size()));
+        CHK(hipMemcpy(h->nrm_gen_d, nrm_gen.data(), nrm_gen.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (h->gen_update) {
+            CHK(dalloc(&h->Heps_d, (size_t)G * nn));
+            CHK(dalloc(&h->partial_d, (size_t)h->gen_tiles * L));
+            CHK(dalloc(&h->du_local_d, (size_t)L));
+            CHK(dalloc(&h->du_total_d, (size_t)L));
+            CHK(hipHostMalloc((void **)&h->du_host, (size_t)L * sizeof(double), hipHostMallocDefault));
+        }
+    }
     CHK(dalloc(&h->nrm_d, nrm.size()));
     CHK(hipMemcpy(h->nrm_d, nrm.data(), nrm.size() * sizeof(double), hipMemcpyHostToDevice));
     CHK(dalloc(&h->present_d, (size_t)G));
@@ -528,7 +701,7 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     CHK(dalloc(&h->eps_b, (size_t)L * NT));
     CHK(dalloc(&h->S_d, (size_t)L * NT));
     CHK(dalloc(&h->lambda_d, L));
-    CHK(dalloc(&h->gint_d, KR_LMAX_CAP));
+    CHK(dalloc(&h->gint_d, std::max(L, KR_LMAX_CAP)));
     const size_t slab = (size_t)h->Kp * N;
     CHK(dalloc(&h->psi0_d, slab));
     CHK(dalloc(&h->tgt_d, slab));
@@ -540,7 +713,7 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     // (NT * NP^2 * 16 B) within a budget; KROTOV_HIP_PRECOMP=0 keeps the Taylor sweeps.
     {
         const size_t ubytes = (size_t)G * NT * NP * NP * sizeof(double2);
-        h->precomp = (NP <= 64) && env_int("KROTOV_HIP_PRECOMP", 1) != 0 && ubytes <= ((size_t)8 << 30);
+        h->precomp = h->fast_ok && (NP <= 64) && env_int("KROTOV_HIP_PRECOMP", 1) != 0 && ubytes <= ((size_t)8 << 30);
         h->use_mfma = env_int("KROTOV_HIP_EXPM_MFMA", 1) != 0;
         if (h->precomp) CHK(dalloc(&h->U_d, (size_t)G * NT * NP * NP));
     }
@@ -550,7 +723,7 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     CHK(hipMemset(h->tgt_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->psiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->chiT_d, 0, slab * sizeof(double2)));
-    CHK(hipMemset(h->gint_d, 0, KR_LMAX_CAP * sizeof(double)));
+    CHK(hipMemset(h->gint_d, 0, std::max(L, KR_LMAX_CAP) * sizeof(double)));
     h->mail_words = (size_t)2 * h->P * 16;  // up to 128-B slots (KR_SLOT_GRANULES <= 16)
     CHK(alloc_mailbox(h, &h->mail_d, h->mail_words, h->P));
     CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
@@ -632,7 +805,7 @@ extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
     if (!h || !info) return KR_ERR_INVALID;
     memset(info, 0, 16 * sizeof(int32_t));
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
-    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay; info[12] = (h->herm && h->NP <= 64) ? 1 : 0; info[13] = h->mfma_sweep ? 1 : 0;
+    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay; info[12] = (h->herm && h->NP <= 64) ? 1 : 0; info[13] = h->mfma_sweep ? 1 : 0; info[14] = h->gen_known ? 1 : 0; info[15] = (h->gen_update ? 1 : 0) | (h->exchange << 4);
     if (h->mfma_sweep) info[3] = 256;
     // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
     return KR_OK;
@@ -727,6 +900,77 @@ static int rowsplit_prelaunch(kr_handle *h, KrSweepArgs &a) {
     return KR_OK;   // (the status words are sticky: only check_status clears them)
 }
 
+// ---- generic (multi-pass) sweeps -------------------------------------------------------------------
+static void gen_args(kr_handle *h, KrGenArgs &g) {
+    memset(&g, 0, sizeof g);
+    g.gen_stride = h->col_stride;
+    g.Heps = h->Heps_d;
+    g.tile_gen = (h->G > 1) ? h->tile_gen_d : nullptr;
+    g.nrm = h->nrm_gen_d;
+    g.present = h->present_d;
+    g.dt = h->dt_d;
+    g.tol = h->tol;
+    memcpy(g.thr, h->thr, sizeof g.thr);
+    g.N = h->cfg.N; g.NT = h->cfg.NT; g.Kp = h->Kp; g.L = h->cfg.L; g.G = h->G;
+    g.KTG = h->KTG; g.RP = h->RP; g.JQ = h->JQg; g.tiles = h->gen_tiles;
+}
+
+static int launch_known_generic(kr_handle *h, const double *eps_dev, bool backward, const double2 *init, double2 *store, double2 *fin) {
+    KrGenArgs g;
+    gen_args(h, g);
+    g.H = backward ? h->Hcol_bw : h->Hcol_fw;
+    g.eps = eps_dev;
+    g.init = init; g.store = store; g.fin = fin;
+    g.dir = backward ? -1 : +1;
+    HIPCHK(h, kr_launch_generic(0, h->KTG, h->gen_tiles, h->gen_lds, h->stream, &g));
+    return KR_OK;
+}
+
+// Stepped update sweep (kr_device_generic.h): partial sums -> reduce -> exchange -> pulse update + H(eps_new) -> forward step,
+// once per time step.  Exchange: none (one rank), ncclAllReduce on the handle's stream, or the host callback.
+static int launch_update_stepped(kr_handle *h, const double *eps_guess_dev, double *eps_new_dev) {
+    const kr_config &c = h->cfg;
+    const int N = c.N, NT = c.NT, L = c.L;
+    const size_t slab = (size_t)h->Kp * N;
+    KrGenArgs g;
+    gen_args(h, g);
+    g.H = h->Hcol_fw;
+    g.eps = eps_guess_dev; g.alpha = h->S_d; g.eps_new = eps_new_dev; g.g_a_int = h->gint_d;
+    g.init = h->psi0_d; g.state = h->psiT_d; g.store = h->store_fw ? h->Phi_d : nullptr; g.fin = nullptr;
+    g.X = h->X_d; g.partial = h->partial_d; g.du_local = h->du_local_d;
+    g.dir = +1;
+    const bool multi = c.world > 1;
+    if (multi && h->exchange == KR_EXCHANGE_RCCL && !h->rccl_comm)
+        return fail(h, KR_ERR_STATE, "exchange = RCCL with world = %d but kr_rccl_init has not been called", c.world);
+    if (multi && h->exchange == KR_EXCHANGE_CALLBACK && !h->cb)
+        return fail(h, KR_ERR_STATE, "exchange = CALLBACK with world = %d but kr_set_exchange_callback has not been called", c.world);
+    const bool use_rccl = h->exchange == KR_EXCHANGE_RCCL && h->rccl_comm;
+    const bool use_cb = h->exchange == KR_EXCHANGE_CALLBACK && h->cb;
+    g.du_total = (use_rccl || use_cb) ? h->du_total_d : h->du_local_d;
+    HIPCHK(h, hipMemcpyAsync(h->psiT_d, h->psi0_d, slab * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+    if (h->store_fw) HIPCHK(h, hipMemcpyAsync(h->Phi_d, h->psi0_d, slab * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->gint_d, 0, (size_t)L * sizeof(double), h->stream));
+    const int form_grid = (int)(((size_t)h->G * N * N + 255) / 256);
+    for (int n = 0; n < NT; ++n) {
+        g.n = n;
+        HIPCHK(h, kr_launch_generic(1, h->KTG, h->gen_tiles, h->gen_lds, h->stream, &g));
+        HIPCHK(h, kr_launch_generic(2, h->KTG, 1, 0, h->stream, &g));
+        if (use_rccl) {
+            const ncclResult_t r = kr_rccl()->AllReduce(h->du_local_d, h->du_total_d, (size_t)L, ncclDouble, ncclSum, h->rccl_comm, h->stream);
+            if (r != ncclSuccess) return fail(h, KR_ERR_HIP, "ncclAllReduce failed at step %d: %s", n, kr_rccl()->GetErrorString(r));
+        } else if (use_cb) {
+            HIPCHK(h, hipMemcpyAsync(h->du_host, h->du_local_d, (size_t)L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const int crc = h->cb(h->cb_ctx, h->du_host, L);
+            if (crc != 0) return fail(h, KR_ERR_HIP, "exchange callback returned %d at step %d", crc, n);
+            HIPCHK(h, hipMemcpyAsync(h->du_total_d, h->du_host, (size_t)L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
+        HIPCHK(h, kr_launch_generic(3, h->KTG, form_grid, 0, h->stream, &g));
+        HIPCHK(h, kr_launch_generic(4, h->KTG, h->gen_tiles, h->gen_lds, h->stream, &g));
+    }
+    return KR_OK;
+}
+
 static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool backward, const double2 *init, double2 *store, double2 *fin) {
     KrSweepArgs a;
     base_args(h, a);
@@ -737,7 +981,10 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     a.U = h->U_d;
     int rc = ev_mark(h, which_ev, false);
     if (rc) return rc;
-    if (h->rowsplit) {
+    if (h->gen_known) {
+        rc = launch_known_generic(h, eps_dev, backward, init, store, fin);
+        if (rc) return rc;
+    } else if (h->rowsplit) {
         rc = rowsplit_prelaunch(h, a);
         if (rc) return rc;
         HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 0, h->P, h->stream, &a));
@@ -767,6 +1014,13 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
 }
 
 static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_new_dev, int calib_steps = 0) {
+    if (h->gen_update) {
+        int rc0 = ev_mark(h, 2, false);
+        if (rc0) return rc0;
+        rc0 = launch_update_stepped(h, eps_guess_dev, eps_new_dev);
+        if (rc0) return rc0;
+        return ev_mark(h, 2, true);
+    }
     if (h->cfg.world > 1 && !h->peers_connected && !calib_steps)
         return fail(h, KR_ERR_STATE, "world = %d but kr_ipc_connect has not been called", h->cfg.world);
     KrSweepArgs a;
@@ -808,7 +1062,7 @@ static int calibrate_exchange(kr_handle *h) {
     const int fixed = env_int("KROTOV_HIP_POLL_DELAY", -2);
     if (fixed != -2) { h->poll_delay = fixed; return KR_OK; }
     // (N > 64: a step holds ~9 memory round trips of which the exchange is one: not worth 0.2 s of calibration)
-    if (h->P < 64 || h->NP > 64 || !env_int("KROTOV_HIP_CALIBRATE", 1)) return KR_OK;
+    if (h->gen_update || h->P < 64 || h->NP > 64 || !env_int("KROTOV_HIP_CALIBRATE", 1)) return KR_OK;
     const int L = h->cfg.L, NT = h->cfg.NT, steps = std::min(NT, 256);
     const size_t slice = (size_t)h->Kp * h->cfg.N;
     const unsigned epoch_saved = h->epoch_base;   // calibration launches must not advance the tag sequence the ranks share
@@ -1096,6 +1350,42 @@ extern "C" int kr_read_storage(kr_handle *h, int which, int k, int n, double *ou
     return KR_OK;
 }
 
+// ---- per-step exchange outside the kernel ----------------------------------------------------------
+extern "C" int kr_rccl_unique_id_size(void) { return (int)sizeof(ncclUniqueId); }
+
+extern "C" int kr_rccl_get_unique_id(void *id_out) {
+    if (!id_out) return fail(nullptr, KR_ERR_INVALID, "kr_rccl_get_unique_id: null");
+    KrRccl *r = kr_rccl();
+    if (!r) return fail(nullptr, KR_ERR_UNSUPPORTED, "%s", kr_rccl_why());
+    ncclUniqueId id;
+    const ncclResult_t rc = r->GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail(nullptr, KR_ERR_HIP, "ncclGetUniqueId failed: %s", r->GetErrorString(rc));
+    memcpy(id_out, &id, sizeof id);
+    return KR_OK;
+}
+
+extern "C" int kr_rccl_init(kr_handle *h, const void *unique_id) {
+    if (!h || !unique_id) return h ? fail(h, KR_ERR_INVALID, "kr_rccl_init: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    KrRccl *r = kr_rccl();
+    if (!r) return fail(h, KR_ERR_UNSUPPORTED, "%s", kr_rccl_why());
+    if (h->rccl_comm) return fail(h, KR_ERR_STATE, "kr_rccl_init: already initialised");
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    const ncclResult_t rc = r->CommInitRank(&h->rccl_comm, h->cfg.world, id, h->cfg.rank);
+    if (rc != ncclSuccess) { h->rccl_comm = nullptr; return fail(h, KR_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString(rc)); }
+    return KR_OK;
+}
+
+extern "C" int kr_set_exchange_callback(kr_handle *h, kr_allreduce_fn fn, void *ctx) {
+    if (!h) return KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    h->cb = fn;
+    h->cb_ctx = ctx;
+    return KR_OK;
+}
+
 // ---- multi-GPU mailbox wiring --------------------------------------------------------------------
 extern "C" int kr_ipc_handle_size(void) { return (int)sizeof(hipIpcMemHandle_t); }
 
@@ -1103,6 +1393,7 @@ extern "C" int kr_ipc_export(kr_handle *h, void *handle_out) {
     if (!h || !handle_out) return h ? fail(h, KR_ERR_INVALID, "kr_ipc_export: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     if (h->cfg.world <= 1) return fail(h, KR_ERR_STATE, "kr_ipc_export: world = 1");
+    if (h->gen_update) return fail(h, KR_ERR_STATE, "kr_ipc_export: this handle exchanges per step (RCCL / callback), it has no mailboxes to wire");
     HIPCHK(h, hipSetDevice(h->device));
     hipIpcMemHandle_t mh;
     HIPCHK(h, hipIpcGetMemHandle(&mh, h->xmail_d));

@@ -15,7 +15,7 @@ from . import _capi as capi
 
 class HipEngine:
     def __init__(self, H0, Hc, tlist, K, *, hc_present=None, traj_generator=None, store_fw=True, prop_tol=0.0,
-                 device=-1, rank=0, world=1, K_global=0):
+                 device=-1, rank=0, world=1, K_global=0, exchange=0, prop_method=0, max_workgroups=0, devices=None):
         """H0 (N,N) and Hc (L,N,N) for a generator shared by all trajectories, or H0 (G,N,N), Hc (G,L,N,N)
         with traj_generator[k] in 0..G-1 for per-trajectory generators (control_derivs[k][l],
         /root/reference/src/workspace.jl:74)."""
@@ -58,6 +58,14 @@ class HipEngine:
         cfg.prop_tol = float(prop_tol)
         cfg.device = device
         cfg.rank, cfg.world, cfg.K_global = rank, world, K_global
+        cfg.exchange, cfg.prop_method, cfg.max_workgroups = int(exchange), int(prop_method), int(max_workgroups)
+        if devices is not None:
+            if not 1 <= len(devices) <= 8:
+                raise ValueError("devices: 1..8 HIP device ordinals")
+            cfg.n_devices = len(devices)
+            for i, d in enumerate(devices):
+                cfg.devices[i] = int(d)
+        self._cb = None
         rc = lib.kr_create(C.byref(cfg), C.byref(self._h))
         if rc != capi.KR_OK:
             msg = lib.kr_last_error(None)
@@ -205,8 +213,46 @@ class HipEngine:
     def info(self):
         a = (C.c_int32 * 16)()
         self._chk(self._lib.kr_get_info(self._h, a))
-        keys = ["NP", "workgroups", "traj_per_wg", "threads", "KT", "LMAX", "K_padded", "store_fw", "JQ", "precomputed_propagators", "rowsplit_R", "exchange_poll_delay", "hermitian_controls_path", "matrix_core_sweep"]
-        return {k: int(a[i]) for i, k in enumerate(keys)}
+        keys = ["NP", "workgroups", "traj_per_wg", "threads", "KT", "LMAX", "K_padded", "store_fw", "JQ", "precomputed_propagators", "rowsplit_R", "exchange_poll_delay", "hermitian_controls_path", "matrix_core_sweep", "generic_known", "generic_update_exchange"]
+        d = {k: int(a[i]) for i, k in enumerate(keys)}
+        ge = d.pop("generic_update_exchange")
+        d["generic_update"] = ge & 1
+        d["exchange"] = ("auto", "mailbox", "rccl", "callback")[(ge >> 4) & 3]
+        return d
+
+    # per-step exchange outside the kernels (KR_EXCHANGE_RCCL / KR_EXCHANGE_CALLBACK)
+    @staticmethod
+    def _torch_first():
+        """One RCCL per process: PyTorch-ROCm bundles a librccl.so that libkrotov_hip would otherwise map BEFORE torch
+        does; a process that imported torch only afterwards aborted at exit (free(): invalid pointer, measured).  So
+        where torch is installed it is imported first and libkrotov_hip then finds its RCCL already mapped."""
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+    @staticmethod
+    def rccl_unique_id():
+        HipEngine._torch_first()
+        lib = capi.load()
+        buf = (C.c_ubyte * lib.kr_rccl_unique_id_size())()
+        capi.check(lib, None, lib.kr_rccl_get_unique_id(buf))
+        return bytes(buf)
+
+    def rccl_init(self, unique_id):
+        HipEngine._torch_first()
+        self._chk(self._lib.kr_rccl_init(self._h, C.c_char_p(bytes(unique_id))))
+
+    def set_exchange_callback(self, fn):
+        """fn(numpy array of L doubles) must sum the array over all ranks IN PLACE (e.g. a gloo / MPI all-reduce)."""
+        def _tramp(ctx, buf, count):
+            try:
+                fn(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:  # noqa: BLE001 -- never raise across the C boundary
+                return 1
+        self._cb = capi.ALLREDUCE_FN(_tramp)   # keep alive for the life of the handle
+        self._chk(self._lib.kr_set_exchange_callback(self._h, self._cb, None))
 
     # multi-GPU wiring
     def ipc_export(self):

@@ -1,0 +1,188 @@
+"""GPU: the generic (multi-pass) kernels of kr_device_generic.h -- the path behind the capacity limits of the persistent
+kernels (N > 256, L > 4, more trajectories than co-resident workgroups) and the carrier of the per-step exchanges that run
+outside a kernel (RCCL all-reduce, host callback) -- against the CPU oracle, same tolerances as test_gpu_parity.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import krotov_jl_amd as kr
+from krotov_jl_amd import workloads as wl
+from krotov_jl_amd import _capi as capi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_STATE, TOL_PULSE = 1e-11, 1e-10
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _check(oc, p, check_storage=True, **kw):
+    K, N = p["psi0"].shape
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, **kw) as eng:
+        info = eng.info()
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        psiT_o, Phi_o = oc.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"])
+        assert np.max(np.abs(psiT - psiT_o)) < TOL_STATE
+        _, _, chiT = wl.chi_and_JT(p["functional"], psiT_o, p["tgt"])
+        eps_new, ga, psiT1 = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        eps_o, ga_o, psiT1_o, X_o, Phi1_o = oc.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT)
+        assert _rel(eps_new, eps_o) < TOL_PULSE
+        assert np.max(np.abs(ga - ga_o)) < 1e-9 * np.max(np.abs(ga_o)) + 1e-24   # (N = 1: the integrand is rounding noise)
+        assert np.max(np.abs(psiT1 - psiT1_o)) < 1e-9
+        if check_storage:
+            assert np.max(np.abs(eng.storage("bw") - X_o)) < TOL_STATE * max(1.0, np.max(np.abs(X_o)))
+            assert np.max(np.abs(eng.storage("fw") - Phi1_o)) < 1e-10
+        again = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        assert np.array_equal(again[0], eps_new) and np.array_equal(again[2], psiT1)   # run-to-run bitwise
+    return info
+
+
+def test_generic_kernels_forced_on_small_shapes(oracle_c, monkeypatch):
+    """KROTOV_HIP_GENERIC=1: every sweep on the generic kernels, shapes the persistent kernels also cover."""
+    monkeypatch.setenv("KROTOV_HIP_GENERIC", "1")
+    for (N, NT, K, L, seed) in [(1, 4, 2, 1, 301), (2, 6, 1, 1, 302), (7, 9, 5, 2, 303), (16, 12, 9, 3, 304), (33, 8, 6, 2, 305),
+                                (64, 6, 10, 2, 306), (100, 4, 3, 1, 307)]:
+        info = _check(oracle_c, wl.dense_problem(N, NT, K, L, seed, 0.1, 1.0))
+        assert info["generic_known"] == 1 and info["generic_update"] == 1
+    p = wl.dense_problem(12, 8, 4, 1, 308, 0.1, 20.0)    # ||H dt|| > 1: sub-steps
+    p["H0"] = p["H0"] * 40.0
+    _check(oracle_c, p)
+    rng = np.random.default_rng(5)
+    p = wl.dense_problem(10, 15, 4, 2, 309, 0.1, 1.0)    # non-Hermitian, non-uniform grid
+    p["H0"] = p["H0"] - 0.05j * np.diag(rng.uniform(0, 1, 10)) + 0.02 * rng.normal(size=(10, 10))
+    p["tlist"] = np.cumsum(np.r_[0.0, rng.uniform(0.05, 0.2, 15)])
+    _check(oracle_c, p)
+
+
+def test_beyond_the_capacity_of_the_persistent_kernels(oracle_c):
+    """N > 256, L > 4 and more trajectories than 256 co-resident workgroups can carry: no KR_ERR_UNSUPPORTED any more
+    (the reference has no such limits, /root/reference/src/workspace.jl:128-161) -- the generic kernels take over."""
+    info = _check(oracle_c, wl.dense_problem(300, 3, 2, 1, 311, 0.02, 1.0), check_storage=False)
+    assert info["generic_known"] == 1 and info["generic_update"] == 1
+    info = _check(oracle_c, wl.dense_problem(9, 10, 5, 6, 312, 0.1, 1.0))           # six controls
+    assert info["generic_update"] == 1
+    info = _check(oracle_c, wl.dense_problem(64, 3, 1100, 2, 313, 0.05, 5.0), check_storage=False)   # K = 1100 at N = 64
+    assert info["generic_update"] == 1 and info["K_padded"] >= 1100
+
+
+def test_generic_with_generators_and_masks(oracle_c, monkeypatch):
+    monkeypatch.setenv("KROTOV_HIP_GENERIC", "1")
+    import krotov_oracle as o
+    rng = np.random.default_rng(78)
+    N, NT, L, G, K = 11, 12, 2, 3, 9
+    tg = np.array([0, 2, 1, 0, 2, 2, 1, 0, 1], np.int32)
+    base = wl.dense_problem(N, NT, K, L, 320, 0.1, 1.5)
+    H0 = np.array([base["H0"] * (1.0 + 0.1 * g) + 0.05 * wl.random_hermitian(rng, N) for g in range(G)])
+    Hc = np.array([[base["Hc"][l] * (1.0 - 0.07 * g) for l in range(L)] for g in range(G)])
+    present = np.ones((G, L), np.uint8)
+    present[2, 0] = 0
+    tl, eps, S, lam, psi0, tgt = base["tlist"], base["eps"], base["S"], base["lam"], base["psi0"], base["tgt"]
+    with kr.HipEngine(H0, Hc, tl, K, traj_generator=tg, hc_present=present) as eng:
+        assert eng.info()["generic_update"] == 1
+        eng.set_initial_states(psi0)
+        psiT = eng.forward(eps)
+        _, _, chiT = wl.chi_and_JT("ss", psiT, tgt)
+        eps_new, ga, psiT1 = eng.iteration(eps, chiT, S, lam)
+    X = [o.backward(H0[tg[k]], Hc[tg[k]], tl, eps, chiT[k:k + 1])[:, 0] for k in range(K)]
+    psi, eps_o = psi0.copy(), eps.copy()
+    for n in range(NT):
+        du = np.zeros(L)
+        for l in range(L):
+            for k in range(K):
+                if present[tg[k], l]:
+                    du[l] += np.vdot(X[k][n], Hc[tg[k], l] @ psi[k]).imag
+        eps_o[:, n] = eps[:, n] + S[:, n] / lam * du
+        for k in range(K):
+            psi[k] = o.step_propagator(H0[tg[k]], Hc[tg[k]], eps_o[:, n], tl[n + 1] - tl[n]) @ psi[k]
+    assert _rel(eps_new, eps_o) < TOL_PULSE and np.max(np.abs(psiT1 - psi)) < 1e-10
+
+
+@pytest.mark.parametrize("exchange", [capi.KR_EXCHANGE_RCCL, capi.KR_EXCHANGE_CALLBACK])
+def test_stepped_update_sweep_one_rank(oracle_c, exchange):
+    """exchange = RCCL / CALLBACK on one rank: the known-pulse sweeps stay on the persistent kernels, the update sweep runs
+    step by step (partial -> reduce -> exchange -> pulse update -> forward step).  RCCL: a world-1 communicator really is
+    created (librccl loaded with dlopen) and ncclAllReduce really runs once per step."""
+    p = wl.dense_problem(20, 25, 12, 2, 330, 0.1, 1.0)
+    calls = []
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 12, exchange=exchange) as eng:
+        info = eng.info()
+        assert info["generic_known"] == 0 and info["generic_update"] == 1
+        assert info["exchange"] == ("rccl" if exchange == capi.KR_EXCHANGE_RCCL else "callback")
+        if exchange == capi.KR_EXCHANGE_RCCL:
+            eng.rccl_init(kr.HipEngine.rccl_unique_id())
+        else:
+            eng.set_exchange_callback(lambda buf: calls.append(buf.copy()))
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+        eps_new, ga, psiT1 = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+    eps_o, ga_o, psiT1_o, _, _ = oracle_c.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT)
+    assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < 1e-9 and np.max(np.abs(psiT1 - psiT1_o)) < 1e-10
+    if exchange == capi.KR_EXCHANGE_CALLBACK:
+        assert len(calls) == 25 and calls[0].shape == (2,)
+
+
+def _cb_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import krotov_jl_amd as kr2
+    from krotov_jl_amd import workloads as wl2
+    from krotov_jl_amd.distributed import shard_range
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        p = wl2.dense_problem(24, 30, 21, 2, 340, 0.1, 1.0)
+        K = 21
+        a, b = shard_range(K, rank, world)
+        eng = kr2.HipEngine(p["H0"], p["Hc"], p["tlist"], b - a, device=0, rank=rank, world=world, K_global=K,
+                            exchange=capi.KR_EXCHANGE_CALLBACK)
+
+        def allreduce(buf):
+            t = torch.from_numpy(buf)       # shares memory: summed in place
+            dist.all_reduce(t)
+        eng.set_exchange_callback(allreduce)
+        eng.set_initial_states(p["psi0"][a:b])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl2.chi_and_JT("ss", psiT, p["tgt"][a:b], K_global=K)
+        eps, ga, psiT = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        q.put((rank, eps, ga, psiT))
+        dist.barrier()
+        eng.close()
+        dist.destroy_process_group()
+    except Exception as exc:  # noqa: BLE001
+        q.put((rank, "ERROR: %r" % (exc,), None, None))
+        raise
+
+
+def test_callback_exchange_two_ranks_vs_unsharded_oracle(oracle_c):
+    """Two ranks sharing the GPU, the per-step sum crossing them through a HOST callback (a gloo all-reduce here; an MPI
+    all-reduce from Julia in production): equal to the unsharded oracle, identical pulses on both ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_cb_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = {}
+    for _ in range(2):
+        rank, eps, ga, psiT = q.get(timeout=240)
+        assert not isinstance(eps, str), eps
+        got[rank] = (eps, ga, psiT)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    p = wl.dense_problem(24, 30, 21, 2, 340, 0.1, 1.0)
+    psiT_o, _ = oracle_c.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False)
+    _, _, chiT = wl.chi_and_JT("ss", psiT_o, p["tgt"])
+    eps_o, ga_o, psiT1_o, _, _ = oracle_c.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT)
+    assert _rel(got[0][0], eps_o) < TOL_PULSE and _rel(got[0][1], ga_o) < 1e-9
+    assert np.max(np.abs(np.concatenate([got[0][2], got[1][2]]) - psiT1_o)) < 1e-9

@@ -255,10 +255,16 @@ def test_rowsplit_with_substeps_and_generators(oracle_c):
     assert info["rowsplit_R"] > 0
 
 
-def test_unsupported_sizes_fail_loudly():
+def test_unsupported_sizes_fail_loudly(monkeypatch):
+    """What no kernel of this build carries fails with KR_ERR_UNSUPPORTED and a message: more than 32 controls; with the
+    generic fallback forbidden (KROTOV_HIP_GENERIC=0) also N > 256."""
+    with pytest.raises(kr.KrotovHipError) as ei:
+        kr.HipEngine(np.eye(4), np.tile(np.eye(4), (33, 1, 1)), np.linspace(0, 1, 3), 1)
+    assert ei.value.code == kr._capi.KR_ERR_UNSUPPORTED
+    monkeypatch.setenv("KROTOV_HIP_GENERIC", "0")
     with pytest.raises(kr.KrotovHipError) as ei:
         kr.HipEngine(np.eye(300), np.eye(300)[None], np.linspace(0, 1, 3), 1)
-    assert ei.value.code == kr._capi.KR_ERR_UNSUPPORTED
+    assert ei.value.code == kr._capi.KR_ERR_UNSUPPORTED and "N = 300" in str(ei.value)
 
 
 @pytest.mark.parametrize("herm", ["0", "2"])
