@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,10 @@ typedef std::complex<double> zc;
 static thread_local std::string g_create_error;
 
 struct kr_handle {
+    // a handle with a device list (kr_config.n_devices > 1) is a GROUP: one shard handle per GPU (rank i of world P), driven
+    // from library-owned threads; all other fields then belong to the shards
+    std::vector<kr_handle *> subs;
+    std::vector<int> k_off;   // [P + 1] first trajectory of every shard
     kr_config cfg{};
     std::string err;
     std::mutex mtx;
@@ -74,10 +79,12 @@ struct kr_handle {
     int poll_delay = -1;  // exchange schedule of the update sweep (KrSweepArgs::poll_delay), set by calibrate_exchange
     unsigned long long *peer_xmail[8]{};
     bool peers_connected = false;
+    bool peers_in_process = false;   // peer mailboxes are plain pointers of sibling shards (device list), not IPC mappings
     unsigned *status_d = nullptr;
     unsigned long long *debug_d = nullptr;
     bool debug_on = false;
     unsigned epoch_base = 0;
+    unsigned func_epoch = 0;   // tag of the cross-rank tau sums (J_T_sm on the device, world > 1)
     bool have_psi0 = false, have_tgt = false, have_X = false, have_final = false, have_params = false;
     // generic (multi-pass) path, kr_device_generic.h: known-pulse sweeps / update sweep run there when the persistent
     // kernels cannot (capacity) or must not (per-step RCCL / callback exchange)
@@ -212,13 +219,54 @@ __global__ void kr_tau_kernel(const double2 *tgt, const double2 *psi, double2 *t
     for (int o = 1; o < 64; o <<= 1) { sr += __shfl_xor(sr, o, 64); si += __shfl_xor(si, o, 64); }
     if (lane == 0) tau[k] = make_double2(sr, si);
 }
-// serial, fixed-order sum of the K taus (K is small); single thread.
-__global__ void kr_tausum_kernel(const double2 *tau, double2 *out, int K) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double sr = 0, si = 0;
-        for (int k = 0; k < K; ++k) { sr += tau[k].x; si += tau[k].y; }
-        out[0] = make_double2(sr, si);
+// Fixed-order sum of the K local taus (256 threads: strided partial sums, then an LDS tree); with world > 1 the local sum
+// goes into every rank's xmail (tau slots behind the update-sweep slots: [2][8][4] granules {tag32 | half of a double},
+// system-scope stores over xGMI / IPC) and kr_taugather_kernel adds the ranks' sums in rank order -- J_T_sm couples ALL
+// trajectories (chi_k = (sum_j tau_j) / K^2 tgt_k, /root/reference/src/optimize.jl:297-302 with make_chi for J_T_sm).
+#define KR_XMAIL_TAU_OFF (2 * 8 * 2 * KR_LMAX_CAP)
+struct KrPeers { unsigned long long *p[8]; };
+__global__ __launch_bounds__(256) void kr_tausum_kernel(const double2 *tau, double2 *out, int K, int world, int rank, unsigned tag, KrPeers peers) {
+    __shared__ double sr[256], si[256];
+    double ar = 0, ai = 0;
+    for (int k = threadIdx.x; k < K; k += 256) { ar += tau[k].x; ai += tau[k].y; }
+    sr[threadIdx.x] = ar; si[threadIdx.x] = ai;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sr[threadIdx.x] += sr[threadIdx.x + o]; si[threadIdx.x] += si[threadIdx.x + o]; }
+        __syncthreads();
     }
+    if (world <= 1) { if (threadIdx.x == 0) out[0] = make_double2(sr[0], si[0]); return; }
+    if ((int)threadIdx.x < 4 * world) {
+        const int r = threadIdx.x >> 2, g = threadIdx.x & 3, par = (int)(tag & 1u);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(g < 2 ? sr[0] : si[0]);
+        const unsigned half = (g & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store(peers.p[r] + KR_XMAIL_TAU_OFF + ((size_t)par * 8 + rank) * 4 + g, ((unsigned long long)tag << 32) | half,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ void kr_taugather_kernel(unsigned long long *xmail, double2 *out, int world, unsigned tag, unsigned *status) {
+    const int lane = threadIdx.x, par = (int)(tag & 1u);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    double re = 0, im = 0;
+    for (;;) {
+        bool ok = true;
+        if (lane < world) {
+            unsigned long long g[4];
+            for (int q = 0; q < 4; ++q) g[q] = __hip_atomic_load(xmail + KR_XMAIL_TAU_OFF + ((size_t)par * 8 + lane) * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int q = 0; q < 4; ++q) ok = ok && ((unsigned)(g[q] >> 32) == tag);
+            re = __longlong_as_double((long long)((g[1] << 32) | (g[0] & 0xffffffffull)));
+            im = __longlong_as_double((long long)((g[3] << 32) | (g[2] & 0xffffffffull)));
+        }
+        if (__all(ok)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > KR_SPIN_TIMEOUT_TICKS) {
+            if (lane == 0) { status[1] = 4u; status[2] = tag; __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    double tr = 0, ti = 0;
+    for (int r = 0; r < world; ++r) { tr += __shfl(re, r, 64); ti += __shfl(im, r, 64); }   // rank order: identical on every rank
+    if (lane == 0) out[0] = make_double2(tr, ti);
 }
 // chi_k(T) for J_T_sm / J_T_ss / J_T_re [QuantumControl.Functionals make_chi], weights 1.
 __global__ void kr_chi_kernel(int functional, const double2 *tgt, const double2 *tau, const double2 *tausum,
@@ -474,7 +522,7 @@ static void free_all(kr_handle *h) {
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d,
                     h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (h->peers_connected)
+    if (h->peers_connected && !h->peers_in_process)
         for (int r = 0; r < h->cfg.world; ++r)
             if (r != h->cfg.rank && h->peer_xmail[r]) (void)hipIpcCloseMemHandle(h->peer_xmail[r]);
     if (h->xmail_d) (void)hipFree(h->xmail_d);
@@ -484,7 +532,7 @@ static void free_all(kr_handle *h) {
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
-extern "C" int kr_destroy(kr_handle *h) {
+static int one_destroy(kr_handle *h) {
     if (!h) return KR_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -518,14 +566,14 @@ static hipError_t alloc_mailbox(kr_handle *h, unsigned long long **p, size_t wor
 static int calibrate_exchange(kr_handle *h);  // defined below, next to launch_update
 static int check_status(kr_handle *h);
 
-extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
+static int one_create(const kr_config *cfg, kr_handle **out) {
     if (out) *out = nullptr;
     if (!cfg || !out) return fail(nullptr, KR_ERR_INVALID, "kr_create: null argument");
     if (cfg->abi_version != KR_ABI_VERSION) return fail(nullptr, KR_ERR_INVALID, "kr_create: abi_version %d != %d", cfg->abi_version, KR_ABI_VERSION);
     if (cfg->L <= 0) return fail(nullptr, KR_ERR_INVALID, "no controls in trajectories: cannot optimize");  // workspace.jl:72
     if (cfg->N <= 0 || cfg->NT <= 0 || cfg->K <= 0) return fail(nullptr, KR_ERR_INVALID, "kr_create: N, NT, K must be positive (got %d, %d, %d)", cfg->N, cfg->NT, cfg->K);
     if (!cfg->tlist || !cfg->H0 || !cfg->Hc) return fail(nullptr, KR_ERR_INVALID, "kr_create: tlist, H0, Hc are required");
-    if (cfg->G < 1 || cfg->G > cfg->K) return fail(nullptr, KR_ERR_INVALID, "kr_create: G = %d must be in 1..K", cfg->G);
+    if (cfg->G < 1) return fail(nullptr, KR_ERR_INVALID, "kr_create: G = %d must be >= 1", cfg->G);
     if (cfg->G > 1 && !cfg->traj_generator) return fail(nullptr, KR_ERR_INVALID, "kr_create: G = %d > 1 needs traj_generator", cfg->G);
     if (cfg->traj_generator)
         for (int k = 0; k < cfg->K; ++k)
@@ -734,7 +782,7 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     CHK(hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
     if (cfg->world > 1) {
         // inter-GPU mailbox: written by peers over xGMI, polled by this GPU's kernels -> uncached/fine-grained
-        const size_t xwords = (size_t)2 * 8 * 2 * KR_LMAX_CAP;
+        const size_t xwords = (size_t)2 * 8 * 2 * KR_LMAX_CAP + 2 * 8 * 4;   // update-sweep slots + tau slots (KR_XMAIL_TAU_OFF)
         // preference: uncached, then fine-grained, then plain device memory (peers always use system-scope atomics)
         if (hipExtMallocWithFlags((void **)&h->xmail_d, xwords * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) {
             (void)hipGetLastError();
@@ -754,14 +802,14 @@ extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     return KR_OK;
 }
 
-extern "C" int kr_set_stream(kr_handle *h, void *hip_stream) {
+static int one_set_stream(kr_handle *h, void *hip_stream) {
     if (!h) return KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return KR_OK;
 }
 
-extern "C" int kr_enable_timing(kr_handle *h, int on) {
+static int one_enable_timing(kr_handle *h, int on) {
     if (!h) return KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     h->timing = on != 0;
@@ -783,7 +831,7 @@ static int ev_mark(kr_handle *h, int kind, bool end) {
     return KR_OK;
 }
 
-extern "C" int kr_get_timings(kr_handle *h, double *t) {
+static int one_get_timings(kr_handle *h, double *t) {
     if (!h || !t) return KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     HIPCHK(h, hipSetDevice(h->device));
@@ -801,7 +849,7 @@ extern "C" int kr_get_timings(kr_handle *h, double *t) {
     return KR_OK;
 }
 
-extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
+static int one_get_info(kr_handle *h, int32_t *info) {
     if (!h || !info) return KR_ERR_INVALID;
     memset(info, 0, 16 * sizeof(int32_t));
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
@@ -811,7 +859,7 @@ extern "C" int kr_get_info(kr_handle *h, int32_t *info) {
     return KR_OK;
 }
 
-extern "C" int kr_debug_stamps(kr_handle *h, unsigned long long *out) {
+static int one_debug_stamps(kr_handle *h, unsigned long long *out) {
     if (!h || !out) return KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     HIPCHK(h, hipSetDevice(h->device));
@@ -834,7 +882,7 @@ static int upload_states(kr_handle *h, double2 *dst, const double *src) {
     return KR_OK;
 }
 
-extern "C" int kr_set_initial_states(kr_handle *h, const double *psi0) {
+static int one_set_initial_states(kr_handle *h, const double *psi0) {
     if (!h || !psi0) return h ? fail(h, KR_ERR_INVALID, "kr_set_initial_states: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     HIPCHK(h, hipSetDevice(h->device));
@@ -845,7 +893,7 @@ extern "C" int kr_set_initial_states(kr_handle *h, const double *psi0) {
     return KR_OK;
 }
 
-extern "C" int kr_set_target_states(kr_handle *h, const double *tgt) {
+static int one_set_target_states(kr_handle *h, const double *tgt) {
     if (!h || !tgt) return h ? fail(h, KR_ERR_INVALID, "kr_set_target_states: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     HIPCHK(h, hipSetDevice(h->device));
@@ -1118,7 +1166,8 @@ static int check_status(kr_handle *h) {
         // sticky until read (launches never clear it, so a failure inside a chain of *_dev calls is not lost)
         HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        const char *what = st[1] == 2 ? "inter-GPU exchange of the update sweep"
+        const char *what = st[1] == 4 ? "cross-rank sum of the taus (J_T_sm)"
+                         : st[1] == 2 ? "inter-GPU exchange of the update sweep"
                          : st[1] == 3 ? "row-split all-gather (the R workgroups of a trajectory)"
                                       : "inter-workgroup exchange of the update sweep";
         return fail(h, KR_ERR_TIMEOUT, "sweep aborted: bounded spin of the %s gave up at %s %u (status code %u); results of this call are invalid",
@@ -1141,7 +1190,7 @@ static int download_states(kr_handle *h, double *dst, const double2 *src) {
     return KR_OK;
 }
 
-extern "C" int kr_forward(kr_handle *h, const double *eps, double *psiT_out) {
+static int one_forward(kr_handle *h, const double *eps, double *psiT_out) {
     if (!h || !eps) return h ? fail(h, KR_ERR_INVALID, "kr_forward: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     if (!h->have_psi0) return fail(h, KR_ERR_STATE, "kr_forward: initial states not set");
@@ -1158,7 +1207,7 @@ extern "C" int kr_forward(kr_handle *h, const double *eps, double *psiT_out) {
     return KR_OK;
 }
 
-extern "C" int kr_backward(kr_handle *h, const double *eps_guess, const double *chiT) {
+static int one_backward(kr_handle *h, const double *eps_guess, const double *chiT) {
     if (!h || !eps_guess || !chiT) return h ? fail(h, KR_ERR_INVALID, "kr_backward: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     HIPCHK(h, hipSetDevice(h->device));
@@ -1188,7 +1237,7 @@ static int set_params_locked(kr_handle *h, const double *S, const double *lambda
     return KR_OK;
 }
 
-extern "C" int kr_set_update_params(kr_handle *h, const double *S, const double *lambda) {
+static int one_set_update_params(kr_handle *h, const double *S, const double *lambda) {
     if (!h || !S || !lambda) return h ? fail(h, KR_ERR_INVALID, "kr_set_update_params: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     HIPCHK(h, hipSetDevice(h->device));
@@ -1221,7 +1270,7 @@ static int update_forward_locked(kr_handle *h, const double *eps_guess, const do
     return KR_OK;
 }
 
-extern "C" int kr_update_forward(kr_handle *h, const double *eps_guess, const double *S, const double *lambda,
+static int one_update_forward(kr_handle *h, const double *eps_guess, const double *S, const double *lambda,
                                  double *eps_new_out, double *g_a_int_out, double *psiT_out) {
     if (!h || !eps_guess || !S || !lambda) return h ? fail(h, KR_ERR_INVALID, "kr_update_forward: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
@@ -1229,7 +1278,7 @@ extern "C" int kr_update_forward(kr_handle *h, const double *eps_guess, const do
     return update_forward_locked(h, eps_guess, S, lambda, eps_new_out, g_a_int_out, psiT_out);
 }
 
-extern "C" int kr_iteration(kr_handle *h, const double *eps_guess, const double *chiT, const double *S,
+static int one_iteration(kr_handle *h, const double *eps_guess, const double *chiT, const double *S,
                             const double *lambda, double *eps_new_out, double *g_a_int_out, double *psiT_out) {
     if (!h || !eps_guess || !chiT || !S || !lambda) return h ? fail(h, KR_ERR_INVALID, "kr_iteration: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
@@ -1247,7 +1296,7 @@ extern "C" int kr_iteration(kr_handle *h, const double *eps_guess, const double 
 }
 
 // ---- device-resident chain ---------------------------------------------------------------------
-extern "C" int kr_forward_dev(kr_handle *h, const void *eps_dev) {
+static int one_forward_dev(kr_handle *h, const void *eps_dev) {
     if (!h || !eps_dev) return h ? fail(h, KR_ERR_INVALID, "kr_forward_dev: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     if (!h->have_psi0) return fail(h, KR_ERR_STATE, "kr_forward_dev: initial states not set");
@@ -1265,22 +1314,29 @@ static int launch_tau(kr_handle *h) {
     return KR_OK;
 }
 
-extern "C" int kr_iteration_functional_dev(kr_handle *h, int functional, const void *eps_guess_dev, void *eps_new_dev) {
+static int one_iteration_functional_dev(kr_handle *h, int functional, const void *eps_guess_dev, void *eps_new_dev) {
     if (!h || !eps_guess_dev || !eps_new_dev) return h ? fail(h, KR_ERR_INVALID, "kr_iteration_functional_dev: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     if (functional < KR_J_T_SM || functional > KR_J_T_RE) return fail(h, KR_ERR_INVALID, "unknown functional %d", functional);
     if (!h->have_psi0 || !h->have_tgt) return fail(h, KR_ERR_STATE, "device chain: initial and target states must be set");
     if (!h->have_final) return fail(h, KR_ERR_STATE, "device chain: no forward sweep has produced final states yet");
     if (!h->have_params) return fail(h, KR_ERR_STATE, "device chain: kr_set_update_params has not been called");
-    if (functional == KR_J_T_SM && h->cfg.world > 1)
-        return fail(h, KR_ERR_UNSUPPORTED, "J_T_sm couples trajectories across ranks; use the host chi path for world > 1");
+    if (functional == KR_J_T_SM && h->cfg.world > 1 && !h->peers_connected)
+        return fail(h, KR_ERR_STATE, "J_T_sm couples trajectories across ranks: the sum of the taus travels through the peer mailboxes (kr_ipc_connect, or a device list)");
     HIPCHK(h, hipSetDevice(h->device));
     const int K = h->Kp, N = h->cfg.N;
     int rc = launch_tau(h);
     if (rc) return rc;
     if (functional == KR_J_T_SM) {
-        hipLaunchKernelGGL(kr_tausum_kernel, dim3(1), dim3(64), 0, h->stream, h->tau_d, h->tausum_d, K);
+        KrPeers peers;
+        for (int r = 0; r < 8; ++r) peers.p[r] = h->peer_xmail[r];
+        const unsigned tag = ++h->func_epoch;
+        hipLaunchKernelGGL(kr_tausum_kernel, dim3(1), dim3(256), 0, h->stream, h->tau_d, h->tausum_d, K, h->cfg.world, h->cfg.rank, tag, peers);
         HIPCHK(h, hipGetLastError());
+        if (h->cfg.world > 1) {
+            hipLaunchKernelGGL(kr_taugather_kernel, dim3(1), dim3(64), 0, h->stream, h->xmail_d, h->tausum_d, h->cfg.world, tag, h->status_d);
+            HIPCHK(h, hipGetLastError());
+        }
     }
     const size_t tot = (size_t)h->Kp * N;
     hipLaunchKernelGGL(kr_chi_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, functional, h->tgt_d,
@@ -1294,14 +1350,14 @@ extern "C" int kr_iteration_functional_dev(kr_handle *h, int functional, const v
     return launch_update(h, (const double *)eps_guess_dev, (double *)eps_new_dev);
 }
 
-extern "C" int kr_synchronize(kr_handle *h) {
+static int one_synchronize(kr_handle *h) {
     if (!h) return KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     HIPCHK(h, hipSetDevice(h->device));
     return check_status(h);
 }
 
-extern "C" int kr_final_states(kr_handle *h, double *psiT_out) {
+static int one_final_states(kr_handle *h, double *psiT_out) {
     if (!h || !psiT_out) return h ? fail(h, KR_ERR_INVALID, "kr_final_states: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     if (!h->have_final) return fail(h, KR_ERR_STATE, "kr_final_states: no sweep has run");
@@ -1312,7 +1368,7 @@ extern "C" int kr_final_states(kr_handle *h, double *psiT_out) {
     return KR_OK;
 }
 
-extern "C" int kr_taus(kr_handle *h, double *tau_out) {
+static int one_taus(kr_handle *h, double *tau_out) {
     if (!h || !tau_out) return h ? fail(h, KR_ERR_INVALID, "kr_taus: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     if (!h->have_final || !h->have_tgt) return fail(h, KR_ERR_STATE, "kr_taus: needs target states and a finished sweep");
@@ -1326,7 +1382,7 @@ extern "C" int kr_taus(kr_handle *h, double *tau_out) {
     return KR_OK;
 }
 
-extern "C" int kr_g_a_int(kr_handle *h, double *out) {
+static int one_g_a_int(kr_handle *h, double *out) {
     if (!h || !out) return h ? fail(h, KR_ERR_INVALID, "kr_g_a_int: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     HIPCHK(h, hipSetDevice(h->device));
@@ -1335,7 +1391,7 @@ extern "C" int kr_g_a_int(kr_handle *h, double *out) {
     return KR_OK;
 }
 
-extern "C" int kr_read_storage(kr_handle *h, int which, int k, int n, double *out) {
+static int one_read_storage(kr_handle *h, int which, int k, int n, double *out) {
     if (!h || !out) return h ? fail(h, KR_ERR_INVALID, "kr_read_storage: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     if (k < 0 || k >= h->cfg.K || n < 0 || n > h->cfg.NT) return fail(h, KR_ERR_INVALID, "kr_read_storage: index (k=%d, n=%d) out of range", k, n);
@@ -1364,7 +1420,7 @@ extern "C" int kr_rccl_get_unique_id(void *id_out) {
     return KR_OK;
 }
 
-extern "C" int kr_rccl_init(kr_handle *h, const void *unique_id) {
+static int one_rccl_init(kr_handle *h, const void *unique_id) {
     if (!h || !unique_id) return h ? fail(h, KR_ERR_INVALID, "kr_rccl_init: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     KrRccl *r = kr_rccl();
@@ -1378,7 +1434,7 @@ extern "C" int kr_rccl_init(kr_handle *h, const void *unique_id) {
     return KR_OK;
 }
 
-extern "C" int kr_set_exchange_callback(kr_handle *h, kr_allreduce_fn fn, void *ctx) {
+static int one_set_exchange_callback(kr_handle *h, kr_allreduce_fn fn, void *ctx) {
     if (!h) return KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     h->cb = fn;
@@ -1389,7 +1445,7 @@ extern "C" int kr_set_exchange_callback(kr_handle *h, kr_allreduce_fn fn, void *
 // ---- multi-GPU mailbox wiring --------------------------------------------------------------------
 extern "C" int kr_ipc_handle_size(void) { return (int)sizeof(hipIpcMemHandle_t); }
 
-extern "C" int kr_ipc_export(kr_handle *h, void *handle_out) {
+static int one_ipc_export(kr_handle *h, void *handle_out) {
     if (!h || !handle_out) return h ? fail(h, KR_ERR_INVALID, "kr_ipc_export: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     if (h->cfg.world <= 1) return fail(h, KR_ERR_STATE, "kr_ipc_export: world = 1");
@@ -1401,7 +1457,7 @@ extern "C" int kr_ipc_export(kr_handle *h, void *handle_out) {
     return KR_OK;
 }
 
-extern "C" int kr_ipc_connect(kr_handle *h, const void *all_handles) {
+static int one_ipc_connect(kr_handle *h, const void *all_handles) {
     if (!h || !all_handles) return h ? fail(h, KR_ERR_INVALID, "kr_ipc_connect: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
     if (h->cfg.world <= 1) return fail(h, KR_ERR_STATE, "kr_ipc_connect: world = 1");
@@ -1417,3 +1473,191 @@ extern "C" int kr_ipc_connect(kr_handle *h, const void *all_handles) {
     h->peers_connected = true;
     return KR_OK;
 }
+
+// ==== one handle, several GPUs (kr_config.n_devices > 1) ================================================
+// The reference threads over trajectories inside ONE process (@threadsif, /root/reference/src/optimize.jl:182,303,321,360);
+// a Julia host therefore wants ONE handle that drives all GPUs of the node.  The group handle block-partitions the
+// trajectories over P shard handles (rank i of world P, one per listed device), wires their exchange in-process (peer access
+// instead of IPC for the mailboxes; ncclCommInitAll for RCCL) and runs every call on all shards from P threads at once --
+// the update sweeps of the shards wait for each other inside their kernels, so they must be in flight together.
+template <class F>
+static int group_run(kr_handle *g, F f) {
+    const int P = (int)g->subs.size();
+    std::vector<int> rcs(P, KR_OK);
+    std::vector<std::thread> th;
+    for (int i = 1; i < P; ++i) th.emplace_back([&rcs, &f, g, i] { rcs[i] = f(g->subs[i], i); });
+    rcs[0] = f(g->subs[0], 0);
+    for (auto &t : th) t.join();
+    for (int i = 0; i < P; ++i)
+        if (rcs[i] != KR_OK) return fail(g, rcs[i], "shard %d of %d (device %d): %s", i, P, g->subs[i]->device, g->subs[i]->err.c_str());
+    return KR_OK;
+}
+static inline bool is_group(const kr_handle *h) { return h && !h->subs.empty(); }
+static inline size_t soff(const kr_handle *g, int i) { return (size_t)g->k_off[i] * g->cfg.N * 2; }   // doubles into a [K][N] complex array
+
+static int group_destroy(kr_handle *g) {
+    for (kr_handle *s : g->subs) if (s) (void)one_destroy(s);
+    delete g;
+    return KR_OK;
+}
+
+static int group_create(const kr_config *cfg, kr_handle **out) {
+    const int P = cfg->n_devices;
+    if (P > 8) return fail(nullptr, KR_ERR_INVALID, "kr_create: n_devices = %d > 8", P);
+    if (cfg->rank != 0 || cfg->world != 1) return fail(nullptr, KR_ERR_INVALID, "kr_create: a device list needs rank = 0, world = 1 (the handle shards by itself)");
+    if (cfg->K < P) return fail(nullptr, KR_ERR_INVALID, "kr_create: K = %d trajectories over %d devices", cfg->K, P);
+    if (cfg->exchange == KR_EXCHANGE_CALLBACK) return fail(nullptr, KR_ERR_UNSUPPORTED, "kr_create: exchange = CALLBACK with a device list (the shards exchange among themselves)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, KR_ERR_NO_DEVICE, "no HIP device available; libkrotov_hip has no CPU fallback");
+    int share[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < P; ++i) {
+        if (cfg->devices[i] < 0 || cfg->devices[i] >= ndev) return fail(nullptr, KR_ERR_INVALID, "kr_create: devices[%d] = %d out of range (%d devices)", i, cfg->devices[i], ndev);
+        for (int j = 0; j < P; ++j) if (cfg->devices[j] == cfg->devices[i]) share[i]++;
+        // Repeating an ordinal is a TEST facility (one-GPU boxes): the shards' kernels wait for each other, so each needs a
+        // hardware queue of its own, and HIP multiplexes a process's streams over few of them (GPU_MAX_HW_QUEUES, default 4;
+        // four shards on one device timed out in their first exchange).
+        if (share[i] > 3) return fail(nullptr, KR_ERR_UNSUPPORTED, "kr_create: device %d is listed %d times; at most 3 shards can share one GPU (hardware queues per process)", cfg->devices[i], share[i]);
+    }
+    kr_handle *g = new kr_handle();
+    g->cfg = *cfg;
+    g->cfg.traj_generator = nullptr; g->cfg.tlist = nullptr; g->cfg.H0 = nullptr; g->cfg.Hc = nullptr; g->cfg.hc_present = nullptr;
+    g->k_off.assign(P + 1, 0);
+    for (int i = 0; i < P; ++i) g->k_off[i + 1] = g->k_off[i] + cfg->K / P + (i < cfg->K % P ? 1 : 0);
+    g->subs.assign(P, nullptr);
+    auto bail = [&](int code) { g_create_error = g->err; (void)group_destroy(g); return code; };
+    for (int i = 0; i < P; ++i) {
+        kr_config c = *cfg;
+        c.n_devices = 0;
+        c.device = cfg->devices[i];
+        c.rank = i; c.world = P;
+        c.K = g->k_off[i + 1] - g->k_off[i];
+        c.K_global = cfg->K;
+        if (cfg->traj_generator) c.traj_generator = cfg->traj_generator + g->k_off[i];
+        if (share[i] > 1) {   // shards that share a GPU split its CUs (their persistent kernels must all be resident at once)
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { fail(g, KR_ERR_HIP, "hipGetDeviceProperties failed"); return bail(KR_ERR_HIP); }
+            const int cap = std::max(1, prop.multiProcessorCount / share[i]);
+            c.max_workgroups = (cfg->max_workgroups > 0) ? std::min(cfg->max_workgroups, cap) : cap;
+        }
+        const int rc = one_create(&c, &g->subs[i]);
+        if (rc != KR_OK) { fail(g, rc, "shard %d (device %d): %s", i, c.device, g_create_error.c_str()); return bail(rc); }
+    }
+    // exchange wiring, in-process
+    const int ex = g->subs[0]->exchange;
+    for (int i = 1; i < P; ++i)
+        if (g->subs[i]->exchange != ex || g->subs[i]->gen_update != g->subs[0]->gen_update) { fail(g, KR_ERR_UNSUPPORTED, "the shards chose different exchange paths (uneven trajectory counts); set kr_config.exchange explicitly"); return bail(KR_ERR_UNSUPPORTED); }
+    if (!g->subs[0]->gen_update) {   // mailboxes: every shard writes into every other shard's xmail directly
+        for (int i = 0; i < P; ++i) {
+            if (hipSetDevice(g->subs[i]->device) != hipSuccess) { fail(g, KR_ERR_HIP, "hipSetDevice failed"); return bail(KR_ERR_HIP); }
+            for (int j = 0; j < P; ++j) {
+                if (g->subs[j]->device != g->subs[i]->device) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(g->subs[j]->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { fail(g, KR_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed: %s", g->subs[i]->device, g->subs[j]->device, hipGetErrorString(e)); return bail(KR_ERR_HIP); }
+                    (void)hipGetLastError();
+                }
+                g->subs[i]->peer_xmail[j] = g->subs[j]->xmail_d;
+            }
+            g->subs[i]->peers_connected = true;
+            g->subs[i]->peers_in_process = true;
+        }
+    } else if (ex == KR_EXCHANGE_RCCL) {
+        KrRccl *r = kr_rccl();
+        if (!r) { fail(g, KR_ERR_UNSUPPORTED, "%s", kr_rccl_why()); return bail(KR_ERR_UNSUPPORTED); }
+        for (int i = 0; i < P; ++i) if (share[i] > 1) { fail(g, KR_ERR_UNSUPPORTED, "exchange = RCCL needs distinct devices (device %d is listed %d times)", cfg->devices[i], share[i]); return bail(KR_ERR_UNSUPPORTED); }
+        std::vector<ncclComm_t> comms(P, nullptr);
+        const ncclResult_t rc = r->CommInitAll(comms.data(), P, cfg->devices);
+        if (rc != ncclSuccess) { fail(g, KR_ERR_HIP, "ncclCommInitAll failed: %s", r->GetErrorString(rc)); return bail(KR_ERR_HIP); }
+        for (int i = 0; i < P; ++i) g->subs[i]->rccl_comm = comms[i];
+    }
+    *out = g;
+    return KR_OK;
+}
+
+// ---- the exported entry points: one handle or a group ---------------------------------------------------
+#define KR_NOGROUP(h, what) if (is_group(h)) return fail(h, KR_ERR_STATE, what ": not available on a handle with a device list")
+extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
+    if (out) *out = nullptr;
+    if (cfg && out && cfg->abi_version == KR_ABI_VERSION && cfg->n_devices > 1) return group_create(cfg, out);
+    return one_create(cfg, out);
+}
+extern "C" int kr_destroy(kr_handle *h) { return is_group(h) ? group_destroy(h) : one_destroy(h); }
+extern "C" int kr_set_stream(kr_handle *h, void *st) { KR_NOGROUP(h, "kr_set_stream"); return one_set_stream(h, st); }
+extern "C" int kr_enable_timing(kr_handle *h, int on) {
+    if (is_group(h)) return group_run(h, [on](kr_handle *s, int) { return one_enable_timing(s, on); });
+    return one_enable_timing(h, on);
+}
+extern "C" int kr_get_timings(kr_handle *h, double *t) { return one_get_timings(is_group(h) ? h->subs[0] : h, t); }
+extern "C" int kr_get_info(kr_handle *h, int32_t *info) { return one_get_info(is_group(h) ? h->subs[0] : h, info); }
+extern "C" int kr_debug_stamps(kr_handle *h, unsigned long long *o) { return one_debug_stamps(is_group(h) ? h->subs[0] : h, o); }
+extern "C" int kr_set_initial_states(kr_handle *h, const double *psi0) {
+    if (is_group(h)) { if (!psi0) return fail(h, KR_ERR_INVALID, "kr_set_initial_states: null"); return group_run(h, [h, psi0](kr_handle *s, int i) { return one_set_initial_states(s, psi0 + soff(h, i)); }); }
+    return one_set_initial_states(h, psi0);
+}
+extern "C" int kr_set_target_states(kr_handle *h, const double *tgt) {
+    if (is_group(h)) { if (!tgt) return fail(h, KR_ERR_INVALID, "kr_set_target_states: null"); return group_run(h, [h, tgt](kr_handle *s, int i) { return one_set_target_states(s, tgt + soff(h, i)); }); }
+    return one_set_target_states(h, tgt);
+}
+extern "C" int kr_forward(kr_handle *h, const double *eps, double *psiT_out) {
+    if (is_group(h)) return group_run(h, [h, eps, psiT_out](kr_handle *s, int i) { return one_forward(s, eps, psiT_out ? psiT_out + soff(h, i) : nullptr); });
+    return one_forward(h, eps, psiT_out);
+}
+extern "C" int kr_backward(kr_handle *h, const double *eps_guess, const double *chiT) {
+    if (is_group(h)) { if (!chiT) return fail(h, KR_ERR_INVALID, "kr_backward: null"); return group_run(h, [h, eps_guess, chiT](kr_handle *s, int i) { return one_backward(s, eps_guess, chiT + soff(h, i)); }); }
+    return one_backward(h, eps_guess, chiT);
+}
+extern "C" int kr_set_update_params(kr_handle *h, const double *S, const double *lambda) {
+    if (is_group(h)) return group_run(h, [S, lambda](kr_handle *s, int) { return one_set_update_params(s, S, lambda); });
+    return one_set_update_params(h, S, lambda);
+}
+extern "C" int kr_update_forward(kr_handle *h, const double *eps_guess, const double *S, const double *lambda, double *eps_new_out,
+                                 double *g_a_int_out, double *psiT_out) {
+    if (is_group(h))   // every shard computes the identical pulse: shard 0 delivers it
+        return group_run(h, [=](kr_handle *s, int i) { return one_update_forward(s, eps_guess, S, lambda, i == 0 ? eps_new_out : nullptr, i == 0 ? g_a_int_out : nullptr, psiT_out ? psiT_out + soff(h, i) : nullptr); });
+    return one_update_forward(h, eps_guess, S, lambda, eps_new_out, g_a_int_out, psiT_out);
+}
+extern "C" int kr_iteration(kr_handle *h, const double *eps_guess, const double *chiT, const double *S, const double *lambda,
+                            double *eps_new_out, double *g_a_int_out, double *psiT_out) {
+    if (is_group(h)) {
+        if (!chiT) return fail(h, KR_ERR_INVALID, "kr_iteration: null");
+        return group_run(h, [=](kr_handle *s, int i) { return one_iteration(s, eps_guess, chiT + soff(h, i), S, lambda, i == 0 ? eps_new_out : nullptr, i == 0 ? g_a_int_out : nullptr, psiT_out ? psiT_out + soff(h, i) : nullptr); });
+    }
+    return one_iteration(h, eps_guess, chiT, S, lambda, eps_new_out, g_a_int_out, psiT_out);
+}
+// device-resident chain on a group: the pulse pointers must be readable and writable from every listed device (memory of
+// one of them -- peer access among the listed devices is enabled at kr_create -- or managed memory); all shards write the
+// identical updated pulse
+extern "C" int kr_forward_dev(kr_handle *h, const void *eps_dev) {
+    if (is_group(h)) return group_run(h, [eps_dev](kr_handle *s, int) { return one_forward_dev(s, eps_dev); });
+    return one_forward_dev(h, eps_dev);
+}
+extern "C" int kr_iteration_functional_dev(kr_handle *h, int functional, const void *eps_guess_dev, void *eps_new_dev) {
+    if (is_group(h)) return group_run(h, [=](kr_handle *s, int) { return one_iteration_functional_dev(s, functional, eps_guess_dev, eps_new_dev); });
+    return one_iteration_functional_dev(h, functional, eps_guess_dev, eps_new_dev);
+}
+extern "C" int kr_synchronize(kr_handle *h) {
+    if (is_group(h)) return group_run(h, [](kr_handle *s, int) { return one_synchronize(s); });
+    return one_synchronize(h);
+}
+extern "C" int kr_final_states(kr_handle *h, double *psiT_out) {
+    if (is_group(h)) { if (!psiT_out) return fail(h, KR_ERR_INVALID, "kr_final_states: null"); return group_run(h, [h, psiT_out](kr_handle *s, int i) { return one_final_states(s, psiT_out + soff(h, i)); }); }
+    return one_final_states(h, psiT_out);
+}
+extern "C" int kr_taus(kr_handle *h, double *tau_out) {
+    if (is_group(h)) { if (!tau_out) return fail(h, KR_ERR_INVALID, "kr_taus: null"); return group_run(h, [h, tau_out](kr_handle *s, int i) { return one_taus(s, tau_out + 2 * (size_t)h->k_off[i]); }); }
+    return one_taus(h, tau_out);
+}
+extern "C" int kr_g_a_int(kr_handle *h, double *out) { return one_g_a_int(is_group(h) ? h->subs[0] : h, out); }
+extern "C" int kr_read_storage(kr_handle *h, int which, int k, int n, double *out) {
+    if (is_group(h)) {
+        if (k < 0 || k >= h->cfg.K) return fail(h, KR_ERR_INVALID, "kr_read_storage: k = %d out of range", k);
+        int i = 0;
+        while (k >= h->k_off[i + 1]) ++i;
+        const int rc = one_read_storage(h->subs[i], which, k - h->k_off[i], n, out);
+        return rc == KR_OK ? rc : fail(h, rc, "%s", h->subs[i]->err.c_str());
+    }
+    return one_read_storage(h, which, k, n, out);
+}
+extern "C" int kr_rccl_init(kr_handle *h, const void *id) { KR_NOGROUP(h, "kr_rccl_init"); return one_rccl_init(h, id); }
+extern "C" int kr_set_exchange_callback(kr_handle *h, kr_allreduce_fn fn, void *ctx) { KR_NOGROUP(h, "kr_set_exchange_callback"); return one_set_exchange_callback(h, fn, ctx); }
+extern "C" int kr_ipc_export(kr_handle *h, void *o) { KR_NOGROUP(h, "kr_ipc_export"); return one_ipc_export(h, o); }
+extern "C" int kr_ipc_connect(kr_handle *h, const void *a) { KR_NOGROUP(h, "kr_ipc_connect"); return one_ipc_connect(h, a); }

@@ -22,6 +22,8 @@ def _problem(which):
         return wl.dense_problem(12, 40, 22, 2, 912, 0.1, 1.0), 22
     if which == "c4_shard":    # the per-GPU shape of BASELINE config 4 on two ranks: N=64, L=2, 64 workgroups per rank (KT = 2)
         return wl.dense_problem(64, 200, 256, 2, 64001, 0.05, 0.05), 256
+    if which == "sm_chain":
+        return wl.dense_problem(12, 30, 10, 2, 914, 0.1, 0.5), 10
     if which == "skewed":      # as "wide"; rank 0 skips the exchange calibration, rank 1 runs it (different launch counts)
         return wl.dense_problem(20, 30, 256, 2, 913, 0.1, 1.0), 256
     if which == "wide":        # 64 workgroups per rank: calibrated exchange schedule + Hermitian-controls kernel variant
@@ -33,7 +35,7 @@ def _problem(which):
 
 def _worker(rank, world, port, q, which="small"):
     sys.path.insert(0, ROOT)
-    os.environ["KROTOV_HIP_MAX_WG"] = "48" if world > 2 else "64"
+    max_wg = 48 if world > 2 else 64   # the ranks share ONE GPU: each takes a share of its CUs (kr_config.max_workgroups)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if which == "skewed" and rank == 0:
@@ -48,7 +50,7 @@ def _worker(rank, world, port, q, which="small"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         p, K = _problem(which)
         a, b = shard_range(K, rank, world)
-        eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], b - a, device=0, rank=rank, world=world, K_global=K)
+        eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], b - a, device=0, rank=rank, world=world, K_global=K, max_workgroups=max_wg)
         connect_peers(eng, dist)
         eng.set_initial_states(p["psi0"][a:b])
         psiT = eng.forward(p["eps"])
@@ -58,6 +60,20 @@ def _worker(rank, world, port, q, which="small"):
             if it == 0:
                 dist.barrier()   # later iterations run unsynchronised: ranks may be a launch apart
             eps, ga, psiT = eng.iteration(eps, chiT, p["S"], p["lam"])
+        if which == "sm_chain":   # device-resident chain with J_T_sm: the sum of the taus crosses the ranks through the mailboxes
+            import torch
+            eng.set_target_states(p["tgt"][a:b])
+            eng.set_update_params(p["S"], p["lam"])
+            e0 = torch.from_numpy(p["eps"].copy()).cuda()
+            e1 = torch.empty_like(e0)
+            torch.cuda.synchronize()
+            eng.forward_dev(e0.data_ptr())
+            dist.barrier()
+            for _ in range(3):
+                eng.iteration_functional_dev(0, e0.data_ptr(), e1.data_ptr())
+                e0, e1 = e1, e0
+            eng.synchronize()
+            eps, ga, psiT = e0.cpu().numpy(), eng.g_a_int(), eng.final_states()
         q.put((rank, eps, ga, psiT))
         dist.barrier()
         eng.close()
@@ -131,3 +147,22 @@ def test_c4_shard_shape_two_ranks_vs_unsharded_oracle(oracle_c):
     assert np.max(np.abs(got[0][0] - eps_o)) / np.max(np.abs(eps_o)) < 1e-10
     assert np.max(np.abs(np.concatenate([got[r][2] for r in range(2)]) - psiT1_o)) < 1e-9
     assert np.max(np.abs(got[0][1] - ga_o)) / np.max(np.abs(ga_o)) < 1e-9
+
+
+def test_device_chain_j_t_sm_two_ranks():
+    """kr_iteration_functional_dev with J_T_sm on two ranks (round 1 refused it for world > 1): every rank needs the sum of
+    ALL taus; it travels through the tau slots of the peer mailboxes.  Against the host-chi chain on one unsharded handle."""
+    sys.path.insert(0, ROOT)
+    import krotov_jl_amd as kr
+    from krotov_jl_amd import workloads as wl
+    got = _run_ranks("sm_chain", 2)
+    p, K = _problem("sm_chain")
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        eps = p["eps"].copy()
+        for _ in range(3):
+            _, _, chiT = wl.chi_and_JT("sm", psiT, p["tgt"])
+            eps, ga, psiT = eng.iteration(eps, chiT, p["S"], p["lam"])
+    assert np.max(np.abs(got[0][0] - eps)) / np.max(np.abs(eps)) < 1e-10
+    assert np.max(np.abs(np.concatenate([got[r][2] for r in range(2)]) - psiT)) < 1e-10
