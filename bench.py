@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", help="C2 | C3 (headline, default) | C4 | C5 (workloads.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "mailbox", "rccl"],
+                    help="N > 1: how the per-step sum of the L update integrands crosses GPUs: in-kernel peer mailboxes over "
+                         "xGMI (default; falls back to rccl if they cannot be wired) or one ncclAllReduce per time step")
     ap.add_argument("--traj", type=int, default=0, help="(testing) override the trajectories per GPU of the config")
     return ap.parse_args()
 
@@ -172,27 +175,52 @@ def main():
         p["psi0"], p["tgt"] = q["psi0"], q["tgt"]
 
     parallelism = "trajectories sharded over %d GPU(s); per-step sum of %d doubles" % (world, L)
+    exchange_used = "none (one GPU)"
     eng = None
     if world > 1:
-        # peer mailboxes over xGMI (IPC-mapped).  Every rank must succeed, otherwise ALL ranks fall back to
-        # independent replicas (no cross-GPU sum) and the JSON line says so.
-        ok = 1
-        try:
-            eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K_local, device=local_rank, rank=rank, world=world,
-                               K_global=K_global)
-            krd.connect_peers(eng, dist)
-        except Exception as exc:  # noqa: BLE001
-            log("rank %d: peer mailbox set-up failed: %r" % (rank, exc))
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if eng is not None:
-                eng.close()
-            eng = None
-            K_global = K_local
-            parallelism = ("REPLICAS ONLY: %d independent copies of the K=%d problem, no cross-GPU reduction "
-                           "(peer mailbox set-up failed)" % (world, K_local))
+        from krotov_jl_amd import _capi as capi
+
+        def all_ok(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+        want = args.exchange
+        if want in ("auto", "mailbox"):
+            # peer mailboxes over xGMI (IPC-mapped); every rank must succeed
+            ok = True
+            try:
+                eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K_local, device=local_rank, rank=rank, world=world,
+                                   K_global=K_global, exchange=capi.KR_EXCHANGE_MAILBOX,
+                                   max_workgroups=int(os.environ.get("KROTOV_BENCH_MAX_WG", "0")))
+                krd.connect_peers(eng, dist)
+            except Exception as exc:  # noqa: BLE001
+                log("rank %d: peer mailbox set-up failed: %r" % (rank, exc))
+                ok = False
+            if all_ok(ok):
+                exchange_used = "in-kernel peer mailboxes over xGMI (hipIpc-mapped), one launch per sweep"
+            else:
+                if eng is not None:
+                    eng.close()
+                eng = None
+                if want == "mailbox":
+                    raise SystemExit("bench.py: --exchange mailbox requested but the peer mailboxes could not be wired on every rank")
+                log("falling back to the per-step RCCL all-reduce on all ranks")
+                want = "rccl"
+        if want == "rccl":
+            ok = True
+            try:
+                eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K_local, device=local_rank, rank=rank, world=world,
+                                   K_global=K_global, exchange=capi.KR_EXCHANGE_RCCL)
+                ids = [kr.HipEngine.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                eng.rccl_init(ids[0])
+            except Exception as exc:  # noqa: BLE001
+                log("rank %d: RCCL set-up failed: %r" % (rank, exc))
+                ok = False
+            if not all_ok(ok):
+                # no silent degradation to independent replicas: a scaling harness must not read that as a scaling point
+                raise SystemExit("bench.py: neither peer mailboxes nor the RCCL exchange could be set up on every rank")
+            exchange_used = "ncclAllReduce (RCCL) of %d doubles per time step between per-step kernels" % L
     if eng is None:
         eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K_local, device=local_rank, K_global=K_global)
     eng.set_initial_states(p["psi0"])
@@ -289,7 +317,7 @@ def main():
                                    % (args.config, p["name"], N,
                                       "dense Hermitian" if np.allclose(p["H0"], p["H0"].conj().T) else "dense non-Hermitian (Liouvillian)",
                                       L, NT, K_local, K_global, p["functional"], p["lam"][0]),
-                       "parallelism": parallelism,
+                       "parallelism": parallelism, "exchange": exchange_used,
                        "engine": info},
             # bound names the unit the dominant kernel computes on: "mfma" = fp64 matrix cores (v_mfma_f64_4x4x4_4b_f64),
             # "valu_fp64" = fp64 vector FMAs; both have the same 78.6 TFLOP/s peak on MI355X.  What BINDS is latency.

@@ -122,6 +122,21 @@ __device__ __forceinline__ void kr_plan_fast(const KrSweepArgs &a, const double 
     }
 }
 
+// Launch, or -- in query mode -- answer how many workgroups of this kernel one CU can hold (kr_create's co-residency check:
+// the persistent kernels wait for each other, so the whole grid must be resident at once).
+struct KrOccQuery { int on, blocks_per_cu; };
+KrOccQuery &kr_occ_query();   // thread-local (krotov_hip.hip)
+template <class Kern>
+static inline void kr_launch_kernel(Kern k, int grid, int threads, size_t lds, hipStream_t s, const KrSweepArgs &a) {
+    KrOccQuery &q = kr_occ_query();
+    if (q.on) {
+        int nb = 0;
+        q.blocks_per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, threads, lds) == hipSuccess) ? nb : -1;
+        return;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, a);
+}
+
 typedef hipError_t (*kr_launch_fn)(int variant_lmax, int variant_kt, int kind, int grid,
                                    hipStream_t stream, const KrSweepArgs *args);
 // kind: 0 = known-pulse sweep (Taylor), 1 = update sweep, 2 = batched propagator build (grid = NT),

@@ -972,12 +972,12 @@ static void kr_launch_expm(int grid, hipStream_t s, const KrSweepArgs *a) {
             constexpr size_t lds = (size_t)4 * 64 * KR_YS * sizeof(double);
             static const bool ok = hipFuncSetAttribute((const void *)kr_expm_mfma64<LM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
             if (ok) {
-                hipLaunchKernelGGL((kr_expm_mfma64<LM>), dim3(grid), dim3(256), lds, s, *a);
+                kr_launch_kernel((kr_expm_mfma64<LM>), grid, 256, lds, s, *a);
                 return;
             }
         }
     }
-    hipLaunchKernelGGL((kr_expm_batch<NP, LM, CB>), dim3(grid), dim3(KrGeom<NP, LM, 1>::THREADS), 0, s, *a);
+    kr_launch_kernel((kr_expm_batch<NP, LM, CB>), grid, KrGeom<NP, LM, 1>::THREADS, 0, s, *a);
 }
 
 template <int NP>
@@ -985,21 +985,21 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
     constexpr int CB = (NP >= 16) ? 4 : 1;
 #define KR_CASE(LM, KTv)                                                                          \
     if (lmax == LM && kt == KTv) {                                                                \
-        if (kind == 0) hipLaunchKernelGGL((kr_sweep_known<NP, LM, KTv>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); \
+        if (kind == 0) kr_launch_kernel((kr_sweep_known<NP, LM, KTv>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
         else if ((kind & 15) == 1) {  /* update sweep: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 */ \
             switch (kind >> 4) { \
-            case 0: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 0, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
-            case 1: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 0, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
-            case 2: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 1, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
-            case 3: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 1, 0>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
-            case 4: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 0, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
-            case 5: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 0, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
-            case 6: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 0, 1, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
-            default: hipLaunchKernelGGL((kr_sweep_update<NP, LM, KTv, 1, 1, 1>), dim3(grid), dim3(KrGeom<NP, LM, KTv>::THREADS), 0, s, *a); break; \
+            case 0: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 0, 0>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            case 1: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 1, 0, 0>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            case 2: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 1, 0>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            case 3: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 1, 1, 0>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            case 4: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            case 5: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 1, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            case 6: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 1, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            default: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 1, 1, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
             } \
         } \
         else if (kind == 2) { kr_launch_expm<NP, LM, CB>(grid, s, a); }                              \
-        else hipLaunchKernelGGL((kr_sweep_apply<NP, KTv>), dim3(grid), dim3(KrApplyGeom<NP>::THREADS), 0, s, *a);      \
+        else kr_launch_kernel((kr_sweep_apply<NP, KTv>), grid, KrApplyGeom<NP>::THREADS, 0, s, *a);      \
         return hipGetLastError();                                                                 \
     }
     KR_CASE(2, 1) KR_CASE(2, 2) KR_CASE(2, 4)

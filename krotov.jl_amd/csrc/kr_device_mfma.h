@@ -444,14 +444,14 @@ static hipError_t kr_launch_mfma64(int tiles, int kind, int grid, hipStream_t s,
 #define KR_CASE_M(TL)                                                                                              \
     if (tiles == TL) {                                                                                             \
         switch (v) {                                                                                               \
-        case 0: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 0, 0>), dim3(grid), dim3(256), 0, s, *a); break;       \
-        case 1: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 0, 0>), dim3(grid), dim3(256), 0, s, *a); break;       \
-        case 2: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 1, 0>), dim3(grid), dim3(256), 0, s, *a); break;       \
-        case 3: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 1, 0>), dim3(grid), dim3(256), 0, s, *a); break;       \
-        case 4: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 0, 1>), dim3(grid), dim3(256), 0, s, *a); break;       \
-        case 5: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 0, 1>), dim3(grid), dim3(256), 0, s, *a); break;       \
-        case 6: hipLaunchKernelGGL((kr_mf_update<LM, TL, 0, 1, 1>), dim3(grid), dim3(256), 0, s, *a); break;       \
-        default: hipLaunchKernelGGL((kr_mf_update<LM, TL, 1, 1, 1>), dim3(grid), dim3(256), 0, s, *a); break;      \
+        case 0: kr_launch_kernel((kr_mf_update<LM, TL, 0, 0, 0>), grid, 256, 0, s, *a); break;       \
+        case 1: kr_launch_kernel((kr_mf_update<LM, TL, 1, 0, 0>), grid, 256, 0, s, *a); break;       \
+        case 2: kr_launch_kernel((kr_mf_update<LM, TL, 0, 1, 0>), grid, 256, 0, s, *a); break;       \
+        case 3: kr_launch_kernel((kr_mf_update<LM, TL, 1, 1, 0>), grid, 256, 0, s, *a); break;       \
+        case 4: kr_launch_kernel((kr_mf_update<LM, TL, 0, 0, 1>), grid, 256, 0, s, *a); break;       \
+        case 5: kr_launch_kernel((kr_mf_update<LM, TL, 1, 0, 1>), grid, 256, 0, s, *a); break;       \
+        case 6: kr_launch_kernel((kr_mf_update<LM, TL, 0, 1, 1>), grid, 256, 0, s, *a); break;       \
+        default: kr_launch_kernel((kr_mf_update<LM, TL, 1, 1, 1>), grid, 256, 0, s, *a); break;      \
         }                                                                                                          \
         return hipGetLastError();                                                                                  \
     }

@@ -454,8 +454,8 @@ template <int NP>
 static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
 #define KR_CASE_R(LM, NRv)                                                                             \
     if (lmax == LM && nr == NRv) {                                                                     \
-        if (kind == 0) hipLaunchKernelGGL((kr_rowsplit_sweep<NP, NRv, LM, false>), dim3(grid), dim3(KrGeomR<NP, NRv, LM>::THREADS), 0, s, *a); \
-        else hipLaunchKernelGGL((kr_rowsplit_sweep<NP, NRv, LM, true>), dim3(grid), dim3(KrGeomR<NP, NRv, LM>::THREADS), 0, s, *a);             \
+        if (kind == 0) kr_launch_kernel((kr_rowsplit_sweep<NP, NRv, LM, false>), grid, KrGeomR<NP, NRv, LM>::THREADS, 0, s, *a); \
+        else kr_launch_kernel((kr_rowsplit_sweep<NP, NRv, LM, true>), grid, KrGeomR<NP, NRv, LM>::THREADS, 0, s, *a);             \
         return hipGetLastError();                                                                      \
     }
     KR_CASE_R(2, 8) KR_CASE_R(2, 16) KR_CASE_R(2, 32) KR_CASE_R(2, 64)

@@ -324,8 +324,8 @@ template <int NP>
 static hipError_t kr_launch_stream_np(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
 #define KR_CASE_S(LM, KTv)                                                                          \
     if (lmax == LM && kt == KTv) {                                                                  \
-        if (kind == 0) hipLaunchKernelGGL((kr_stream_known<NP, LM, KTv>), dim3(grid), dim3(KrGeomS<NP, LM, KTv>::THREADS), 0, s, *a); \
-        else hipLaunchKernelGGL((kr_stream_update<NP, LM, KTv>), dim3(grid), dim3(KrGeomS<NP, LM, KTv>::THREADS), 0, s, *a);          \
+        if (kind == 0) kr_launch_kernel((kr_stream_known<NP, LM, KTv>), grid, KrGeomS<NP, LM, KTv>::THREADS, 0, s, *a); \
+        else kr_launch_kernel((kr_stream_update<NP, LM, KTv>), grid, KrGeomS<NP, LM, KTv>::THREADS, 0, s, *a);          \
         return hipGetLastError();                                                                   \
     }
     KR_CASE_S(2, 1) KR_CASE_S(2, 2) KR_CASE_S(2, 4)

@@ -28,6 +28,7 @@
 typedef std::complex<double> zc;
 
 static thread_local std::string g_create_error;
+KrOccQuery &kr_occ_query() { static thread_local KrOccQuery q{0, 0}; return q; }
 
 struct kr_handle {
     // a handle with a device list (kr_config.n_devices > 1) is a GROUP: one shard handle per GPU (rank i of world P), driven
@@ -465,6 +466,29 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
     int rc = (genv == 1) ? KR_ERR_UNSUPPORTED : make_plan_fast(h, tg, wg_gen, c.max_workgroups);
     h->fast_ok = (rc == KR_OK);
     if (rc != KR_OK && rc != KR_ERR_UNSUPPORTED) return rc;
+    if (h->fast_ok) {
+        // Co-residency: the P persistent workgroups of an update sweep spin on each other, so all of them must be resident
+        // at once.  Ask the runtime how many workgroups of the update kernel one CU holds (registers, LDS) and fail fast --
+        // or move to the generic kernels -- instead of launching a grid that would sit in its bounded spin.  (What the
+        // runtime cannot know -- other processes on the same GPU -- is the caller's to declare: kr_config.max_workgroups.)
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+        KrOccQuery &q = kr_occ_query();
+        KrSweepArgs dummy;
+        memset(&dummy, 0, sizeof dummy);
+        q.on = 1; q.blocks_per_cu = -2;
+        if (h->rowsplit) (void)h->launch_rs(h->LMAXv, h->NR, 1, h->P, nullptr, &dummy);
+        else if (h->mfma_sweep) (void)kr_launch_mf64(h->LMAXv, h->KT / 2, 1, h->P, nullptr, &dummy);
+        else (void)h->launch(h->LMAXv, h->KT, 1, h->P, nullptr, &dummy);
+        q.on = 0;
+        const long long room = (long long)std::max(q.blocks_per_cu, 0) * prop.multiProcessorCount;
+        if (q.blocks_per_cu != -2 && room < h->P) {
+            fail(h, KR_ERR_UNSUPPORTED, "the update sweep needs %d co-resident workgroups but this device holds %lld of them (%d per CU x %d CUs)",
+                 h->P, room, q.blocks_per_cu, prop.multiProcessorCount);
+            h->fast_ok = false;
+            rc = KR_ERR_UNSUPPORTED;
+        }
+    }
     if (!h->fast_ok && genv == 0) return rc;
     // exchange
     int ex = c.exchange;

@@ -101,3 +101,23 @@ def test_device_list_errors():
             eng.ipc_export()                        # a device list wires itself
         with pytest.raises(kr.KrotovHipError):
             eng.read_storage("bw", 6, 0)
+
+
+def test_max_workgroups_is_honoured(oracle_c):
+    """kr_config.max_workgroups: a handle that shares its GPU with others declares its share of the CUs; the plan packs
+    more trajectories per workgroup (or moves to the generic kernels) instead of launching more persistent workgroups."""
+    p = wl.dense_problem(16, 20, 40, 1, 530, 0.1, 1.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 40, max_workgroups=8) as eng:
+        info = eng.info()
+        assert info["workgroups"] <= 8 and info["generic_update"] == 0
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+        eps_new, ga, psiT1 = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+    eps_o = oracle_c.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT)[0]
+    assert _rel(eps_new, eps_o) < 1e-10
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 40, max_workgroups=2) as eng:   # 40 trajectories on 2 workgroups: generic kernels
+        assert eng.info()["generic_update"] == 1
+        eng.set_initial_states(p["psi0"])
+        eng.forward(p["eps"])
+        assert _rel(eng.iteration(p["eps"], chiT, p["S"], p["lam"])[0], eps_o) < 1e-10
