@@ -182,6 +182,14 @@ struct KrGenArgs {
     double tol;
     double thr[KR_MAX_ORDER];
     int N, NT, Kp, L, G, KTG, RP, JQ, tiles, dir, n;
+    // step propagator (kr_prop_method): per-step tables of the polynomial methods (kr_gen_propagate)
+    int method, ptab_stride;
+    const double *ptab;
+    const double *erange;      // [L] control range the polynomial methods were initialised for (update sweep), or nullptr
+    unsigned *status;
 };
+// values of KrGenArgs::method = enum kr_prop_method of include/krotov_hip.h (device code does not see that header)
+#define KR_METHOD_CHEBY 2
+#define KR_METHOD_NEWTON 3
 
 hipError_t kr_launch_generic(int kind, int ktg, int grid, size_t lds_bytes, hipStream_t s, const KrGenArgs *a);

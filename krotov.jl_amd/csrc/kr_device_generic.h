@@ -81,28 +81,93 @@ __device__ __forceinline__ void kr_gen_matvec(const KrGenArgs &a, const double2 
     __syncthreads();
 }
 
-// psi (LDS, [KTG][N]) <- exp(-i sdt sum_m c_m M_m) psi by Horner/Taylor with sub-stepping; y0, y1: LDS scratch vectors
+// psi (LDS, [KTG][N]) <- exp(-i sdt sum_m c_m M_m) psi; y0, y1, y2: LDS scratch vectors.  Three step propagators
+// (kr_config.prop_method, the reference's prop_method: /root/reference/src/optimize.jl:108,137-153):
+//   Taylor     Horner form, order and sub-steps from the norm bound theta of THIS step (kr_taylor_plan)
+//   Chebyshev  (Hermitian generators) exp(-i A) = sum_k (2 - d_k0) (-i)^k J_k(th) T_k(A / th) by Clenshaw's recurrence;
+//              th = |dt| * Lambda with Lambda a bound of the spectral radius over the WHOLE control range the sweep was
+//              initialised for (update sweep: the guess range widened 5x, as transform_control_ranges does, optimize.jl:238-244)
+//   Newton     interpolation polynomial of exp(-i z) at Leja points of [-th, th] in Newton form,
+//              p(A) psi = sum_k d_k prod_{j<k} (A - z_j) psi (divided differences d_k from the host, long double)
+// Per-step tables (host, a.ptab + step * a.ptab_stride): [0] degree d, [1] sub-steps s, [2] th of a sub-step, then
+// Chebyshev: J_0..J_d; Newton: z_0..z_{d-1}, then (re, im) of d_0..d_d.
 template <int KTG>
 __device__ __forceinline__ void kr_gen_propagate(const KrGenArgs &a, const double2 *Hb, const int nmat, const double *c,
-                                                 const double theta, const double sdt, double2 *psi, double2 *y0, double2 *y1,
-                                                 double2 *red) {
+                                                 const double theta, const double sdt, const int step, double2 *psi, double2 *y0,
+                                                 double2 *y1, double2 *y2, double2 *red) {
+    const int tot = KTG * a.N;
+    if (a.method == KR_METHOD_CHEBY || a.method == KR_METHOD_NEWTON) {
+        const double *tab = a.ptab + (size_t)step * a.ptab_stride;
+        const int d = (int)tab[0], s = (int)tab[1];
+        const double th = tab[2];
+        const double fs = sdt / (double)s;          // A = fs * H per sub-step, spectrum within [-th, th]
+        for (int sub = 0; sub < s; ++sub) {
+            if (a.method == KR_METHOD_CHEBY) {
+                // Clenshaw: b_k = c_k psi + 2 At b_{k+1} - b_{k+2}, At = A / th; result = c_0 psi + At b_1 - b_2
+                // vectors: y0 = b_{k+1}, y2 = b_{k+2}, y1 = H b_{k+1}
+                const double sc = fs / th;
+                for (int e = threadIdx.x; e < tot; e += blockDim.x) { y0[e] = make_double2(0.0, 0.0); y2[e] = make_double2(0.0, 0.0); }
+                __syncthreads();
+                for (int k = d; k >= 0; --k) {
+                    const double jk = tab[3 + k] * (k == 0 ? 1.0 : 2.0);
+                    // c_k = jk * (-i)^k
+                    const int q = k & 3;
+                    const double cr = (q == 0) ? jk : ((q == 2) ? -jk : 0.0), ci = (q == 1) ? -jk : ((q == 3) ? jk : 0.0);
+                    if (k < d) kr_gen_matvec<KTG>(a, Hb, nmat, c, y0, y1, red);   // (k = d: b_{d+1} = 0)
+                    const double two = (k == 0) ? 1.0 : 2.0;
+                    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+                        const double2 p = psi[e], b2 = y2[e];
+                        double2 hv = make_double2(0.0, 0.0);
+                        if (k < d) hv = y1[e];
+                        const double nr = cr * p.x - ci * p.y + two * sc * hv.x - b2.x;
+                        const double ni = cr * p.y + ci * p.x + two * sc * hv.y - b2.y;
+                        y2[e] = y0[e];                       // b_{k+2} <- b_{k+1}
+                        y0[e] = make_double2(nr, ni);        // b_k  (k = 0: the result)
+                    }
+                    __syncthreads();
+                }
+                for (int e = threadIdx.x; e < tot; e += blockDim.x) psi[e] = y0[e];
+                __syncthreads();
+            } else {
+                // Newton: w_0 = psi, acc = d_0 w_0; w_{k+1} = (A - z_k) w_k = fs H w_k - z_k w_k; acc += d_{k+1} w_{k+1}
+                const double *z = tab + 3, *dd = tab + 3 + d;
+                for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+                    const double2 p = psi[e];
+                    y0[e] = p;
+                    y2[e] = make_double2(dd[0] * p.x - dd[1] * p.y, dd[0] * p.y + dd[1] * p.x);
+                }
+                __syncthreads();
+                for (int k = 0; k < d; ++k) {
+                    kr_gen_matvec<KTG>(a, Hb, nmat, c, y0, y1, red);
+                    const double zr = z[k], dr = dd[2 * (k + 1)], di = dd[2 * (k + 1) + 1];
+                    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+                        const double2 hv = y1[e], w = y0[e], acc = y2[e];
+                        const double wr = fs * hv.x - zr * w.x, wi = fs * hv.y - zr * w.y;
+                        y0[e] = make_double2(wr, wi);
+                        y2[e] = make_double2(acc.x + dr * wr - di * wi, acc.y + dr * wi + di * wr);
+                    }
+                    __syncthreads();
+                }
+                for (int e = threadIdx.x; e < tot; e += blockDim.x) psi[e] = y2[e];
+                __syncthreads();
+            }
+        }
+        return;
+    }
     int s, m;
     kr_gen_plan(a, theta, s, m);
     const double fs = (s == 1) ? sdt : sdt / (double)s;
-    const int tot = KTG * a.N;
     for (int sub = 0; sub < s; ++sub) {
         const double2 *src = psi;
-        double2 *dst = y0;
         for (int j = m; j >= 1; --j) {   // y <- psi + (-i fs / j) H y
             kr_gen_matvec<KTG>(a, Hb, nmat, c, src, y1, red);
             const double f = fs * kr_rinv[j];
-            double2 *target = (j == 1) ? y0 : dst;
             for (int e = threadIdx.x; e < tot; e += blockDim.x) {
                 const double2 hv = y1[e], p = psi[e];
-                target[e] = make_double2(fma(f, hv.y, p.x), fma(-f, hv.x, p.y));
+                y0[e] = make_double2(fma(f, hv.y, p.x), fma(-f, hv.x, p.y));
             }
             __syncthreads();
-            src = target;
+            src = y0;
         }
         for (int e = threadIdx.x; e < tot; e += blockDim.x) psi[e] = y0[e];
         __syncthreads();
@@ -111,7 +176,7 @@ __device__ __forceinline__ void kr_gen_propagate(const KrGenArgs &a, const doubl
 
 #define KR_GEN_LDS(KTG) \
     extern __shared__ __attribute__((aligned(16))) double2 kr_gen_lds[]; \
-    double2 *psi = kr_gen_lds, *y0 = psi + (KTG) * a.N, *y1 = y0 + (KTG) * a.N, *red = y1 + (KTG) * a.N;
+    double2 *psi = kr_gen_lds, *y0 = psi + (KTG) * a.N, *y1 = y0 + (KTG) * a.N, *y2 = y1 + (KTG) * a.N, *red = y2 + (KTG) * a.N;
 
 // known-pulse sweep, one launch: every workgroup runs its tile through all N_T steps (no inter-workgroup dependency)
 template <int KTG>
@@ -134,7 +199,7 @@ __global__ __launch_bounds__(256) void kr_gen_known(const KrGenArgs a) {
         double theta = a.nrm[(size_t)gen * (1 + L)];
         c[0] = 1.0;
         for (int l = 0; l < L; ++l) { c[1 + l] = a.eps[(size_t)l * NT + n]; theta += fabs(c[1 + l]) * a.nrm[(size_t)gen * (1 + L) + 1 + l]; }
-        kr_gen_propagate<KTG>(a, Hb, 1 + L, c, theta * fabs(sdt), sdt, psi, y0, y1, red);
+        kr_gen_propagate<KTG>(a, Hb, 1 + L, c, theta * fabs(sdt), sdt, n, psi, y0, y1, y2, red);
         if (a.store) {
             const int slot = (a.dir > 0) ? (n + 1) : n;
             for (int e = threadIdx.x; e < tot; e += blockDim.x) a.store[(size_t)slot * slab + tb + e] = psi[e];
@@ -210,6 +275,9 @@ __global__ __launch_bounds__(256) void kr_gen_form(const KrGenArgs a) {
         h.x = fma(en, hl.x, h.x);
         h.y = fma(en, hl.y, h.y);
         if (idx == 0) {
+            // Chebyshev / Newton were initialised for |eps_l| <= erange[l] (guess range x 5): an update that leaves it would be
+            // propagated with a polynomial that no longer covers the spectrum -- report instead of returning wrong states
+            if (a.erange && fabs(en) > a.erange[l] && a.status) { a.status[1] = 5u; a.status[2] = (unsigned)n; a.status[0] = 1u; }
             a.eps_new[(size_t)l * NT + n] = en;
             const double ad = fabs(du);
             a.g_a_int[l] = __dadd_rn(a.g_a_int[l], __dmul_rn(__dmul_rn(al, __dmul_rn(ad, ad)), a.dt[n]));   // optimize.jl:356
@@ -230,7 +298,7 @@ __global__ __launch_bounds__(256) void kr_gen_apply(const KrGenArgs a) {
     double theta = a.nrm[(size_t)gen * (1 + L)];
     for (int l = 0; l < L; ++l) theta += fabs(a.eps_new[(size_t)l * NT + n]) * a.nrm[(size_t)gen * (1 + L) + 1 + l];
     const double one = 1.0, dtn = a.dt[n];
-    kr_gen_propagate<KTG>(a, a.Heps + (size_t)gen * N * N, 1, &one, theta * fabs(dtn), dtn, psi, y0, y1, red);
+    kr_gen_propagate<KTG>(a, a.Heps + (size_t)gen * N * N, 1, &one, theta * fabs(dtn), dtn, n, psi, y0, y1, y2, red);
     for (int e = threadIdx.x; e < tot; e += blockDim.x) {
         a.state[tb + e] = psi[e];
         if (a.store) a.store[(size_t)(n + 1) * slab + tb + e] = psi[e];

@@ -98,6 +98,12 @@ struct kr_handle {
     double *nrm_gen_d = nullptr, *partial_d = nullptr, *du_local_d = nullptr, *du_total_d = nullptr;
     double *du_host = nullptr;   // pinned, callback exchange
     int exchange = KR_EXCHANGE_AUTO;   // resolved at kr_create
+    int method = KR_PROP_AUTO;         // kr_prop_method; Chebyshev / Newton run on the generic kernels
+    double *ptab_d = nullptr, *erange_d = nullptr;
+    int ptab_stride = 0;
+    double lam0 = 0.0;                 // max over generators of the norm bound of H0
+    std::vector<double> lam_l;         // [L] the same for H_l
+    std::vector<double> dt_host, ptab_host, eps_stage;
     kr_allreduce_fn cb = nullptr;
     void *cb_ctx = nullptr;
     ncclComm_t rccl_comm = nullptr;
@@ -446,10 +452,10 @@ static int gen_geometry(kr_handle *h, int ktile_limit) {
     while (rp < N && rp < 256) rp <<= 1;
     h->RP = rp;
     h->JQg = 256 / rp;
-    auto lds = [&](int ktg) { return ((size_t)3 * ktg * N + (size_t)h->JQg * ktg * rp) * sizeof(double2); };
+    auto lds = [&](int ktg) { return ((size_t)4 * ktg * N + (size_t)h->JQg * ktg * rp) * sizeof(double2); };
     int ktg = 4;
     while (ktg > 1 && (lds(ktg) > 64 * 1024 || (ktile_limit > 0 && ktile_limit % ktg != 0))) ktg >>= 1;
-    if (lds(ktg) > 150 * 1024) return fail(h, KR_ERR_UNSUPPORTED, "N = %d: three state vectors do not fit the CU's LDS (generic kernels)", N);
+    if (lds(ktg) > 150 * 1024) return fail(h, KR_ERR_UNSUPPORTED, "N = %d: four state vectors do not fit the CU's LDS (generic kernels)", N);
     h->KTG = ktg;
     h->gen_lds = lds(ktg);
     return KR_OK;
@@ -463,7 +469,10 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
     const int genv = env_int("KROTOV_HIP_GENERIC", -1);
     if (c.L > 32) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > 32 controls not supported", c.L);
     if (c.exchange < KR_EXCHANGE_AUTO || c.exchange > KR_EXCHANGE_CALLBACK) return fail(h, KR_ERR_INVALID, "kr_create: exchange = %d", c.exchange);
-    int rc = (genv == 1) ? KR_ERR_UNSUPPORTED : make_plan_fast(h, tg, wg_gen, c.max_workgroups);
+    if (c.prop_method < KR_PROP_AUTO || c.prop_method > KR_PROP_NEWTON) return fail(h, KR_ERR_INVALID, "kr_create: prop_method = %d", c.prop_method);
+    h->method = c.prop_method;
+    const bool poly = (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON);   // these live in the generic kernels
+    int rc = (genv == 1 || poly) ? KR_ERR_UNSUPPORTED : make_plan_fast(h, tg, wg_gen, c.max_workgroups);
     h->fast_ok = (rc == KR_OK);
     if (rc != KR_OK && rc != KR_ERR_UNSUPPORTED) return rc;
     if (h->fast_ok) {
@@ -489,7 +498,7 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
             rc = KR_ERR_UNSUPPORTED;
         }
     }
-    if (!h->fast_ok && genv == 0) return rc;
+    if (!h->fast_ok && genv == 0 && !poly) return rc;
     // exchange
     int ex = c.exchange;
     if (ex == KR_EXCHANGE_AUTO) ex = h->fast_ok ? KR_EXCHANGE_MAILBOX : (c.world > 1 ? KR_EXCHANGE_RCCL : KR_EXCHANGE_MAILBOX);
@@ -544,7 +553,7 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d,
-                    h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d};
+                    h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected && !h->peers_in_process)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -713,6 +722,31 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
             }
         CHK(dalloc(&h->Hdense_fw, dense.size()));
         CHK(hipMemcpy(h->Hdense_fw, dense.data(), dense.size() * sizeof(double2), hipMemcpyHostToDevice));
+    }
+    h->lam0 = 0.0;
+    h->lam_l.assign(L, 0.0);
+    for (int g = 0; g < G; ++g) {
+        h->lam0 = std::max(h->lam0, nrm_gen[(size_t)g * (1 + L)]);
+        for (int l = 0; l < L; ++l) h->lam_l[l] = std::max(h->lam_l[l], nrm_gen[(size_t)g * (1 + L) + 1 + l]);
+    }
+    h->dt_host.assign(NT, 0.0);
+    for (int n = 0; n < NT; ++n) h->dt_host[n] = cfg->tlist[n + 1] - cfg->tlist[n];
+    if (h->method == KR_PROP_CHEBY) {   // Chebyshev needs real spectra: every operator exactly Hermitian
+        for (int g = 0; g < G; ++g)
+            for (int m = 0; m <= L; ++m) {
+                const zc *M = (m == 0) ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn;
+                for (int c2 = 0; c2 < N; ++c2)
+                    for (int r = 0; r <= c2; ++r)
+                        if (M[(size_t)c2 * N + r] != std::conj(M[(size_t)r * N + c2])) {
+                            fail(h, KR_ERR_INVALID, "prop_method = CHEBY needs Hermitian generators (operator %d of generator %d is not); use NEWTON or TAYLOR", m, g);
+                            return bail(KR_ERR_INVALID);
+                        }
+            }
+    }
+    if (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON) {
+        h->ptab_stride = 4 + 3 * (KR_MAX_ORDER + 2);
+        CHK(dalloc(&h->ptab_d, (size_t)NT * h->ptab_stride));
+        CHK(dalloc(&h->erange_d, (size_t)L));
     }
     if (h->gen_known || h->gen_update) {
         // generic kernels: the operators column-major as the caller hands them over (+ the adjoint, column-major), the
@@ -972,6 +1006,107 @@ static int rowsplit_prelaunch(kr_handle *h, KrSweepArgs &a) {
     return KR_OK;   // (the status words are sticky: only check_status clears them)
 }
 
+// ---- polynomial step propagators (Chebyshev, Newton): per-step coefficient tables ------------------------
+// Lambda bounds the spectral radius of H(eps) for every eps in the control range [-emax_l, emax_l]; a step with interval
+// dt_n then needs a polynomial good on [-th, th], th = |dt_n| Lambda / s (s sub-steps).  Tables are cached per th (a uniform
+// grid has one).  Row layout: kr_gen_propagate (kr_device_generic.h).
+static int cheby_row(double th, double tol, double *row) {
+    const int kmax = KR_MAX_ORDER + 1;
+    double J[KR_MAX_ORDER + 2];
+    for (int k = 0; k <= kmax; ++k) J[k] = std::cyl_bessel_j((double)k, th);
+    int d = kmax;
+    double tail = 0.0;
+    for (int k = kmax; k >= 1; --k) {   // smallest d whose dropped terms sum below tol
+        tail += 2.0 * std::fabs(J[k]);
+        if (tail > tol) { d = k; break; }
+        d = k - 1;
+    }
+    if (d < 1) d = 1;
+    for (int k = 0; k <= d; ++k) row[3 + k] = J[k];
+    return d;
+}
+static int newton_row(double th, double tol, double *row) {
+    typedef std::complex<long double> lc;
+    const int dmax = KR_MAX_ORDER;
+    // Leja points of [-th, th] from a fine candidate set (greedy: maximise the product of distances)
+    const int NC = 4001;
+    std::vector<long double> cand(NC), logp(NC, 0.0L);
+    for (int i = 0; i < NC; ++i) cand[i] = -(long double)th * std::cos((long double)M_PIl * i / (NC - 1));
+    std::vector<long double> z;
+    z.push_back((long double)th);
+    for (int k = 1; k <= dmax; ++k) {
+        int best = 0;
+        long double bv = -1e300L;
+        for (int i = 0; i < NC; ++i) {
+            const long double dist = std::fabs(cand[i] - z.back());
+            logp[i] += (dist > 0) ? std::log(dist) : -1e300L;
+            if (logp[i] > bv) { bv = logp[i]; best = i; }
+        }
+        z.push_back(cand[best]);
+    }
+    // divided differences of f(z) = exp(-i z)
+    std::vector<lc> dd(dmax + 1);
+    for (int k = 0; k <= dmax; ++k) dd[k] = std::exp(lc(0, -1) * z[k]);
+    for (int j = 1; j <= dmax; ++j)
+        for (int k = dmax; k >= j; --k) dd[k] = (dd[k] - dd[k - 1]) / (z[k] - z[k - j]);
+    // smallest degree whose interpolant is within tol of f on the circle |z| = th (the field of values lies inside it)
+    int d = dmax;
+    for (int cand_d = 1; cand_d <= dmax; ++cand_d) {
+        long double err = 0;
+        for (int q = 0; q < 48; ++q) {
+            const lc zz = std::polar((long double)th, 2.0L * M_PIl * q / 48);
+            lc acc = dd[cand_d];
+            for (int k = cand_d - 1; k >= 0; --k) acc = acc * (zz - z[k]) + dd[k];
+            err = std::max(err, std::abs(acc - std::exp(lc(0, -1) * zz)));
+        }
+        if (err <= (long double)tol * 4) { d = cand_d; break; }
+    }
+    for (int k = 0; k < d; ++k) row[3 + k] = (double)z[k];
+    for (int k = 0; k <= d; ++k) { row[3 + d + 2 * k] = (double)dd[k].real(); row[3 + d + 2 * k + 1] = (double)dd[k].imag(); }
+    return d;
+}
+// eps_dev: the pulses of this sweep ([L][NT], device); widen: factor on the control range (1 for known pulses, 5 for the update
+// sweep, whose pulses are only known as it goes: transform_control_ranges, optimize.jl:238-244)
+static int build_poly_tables(kr_handle *h, const double *eps_dev, double widen) {
+    const int L = h->cfg.L, NT = h->cfg.NT;
+    h->eps_stage.resize((size_t)L * NT);
+    HIPCHK(h, hipMemcpyAsync(h->eps_stage.data(), eps_dev, (size_t)L * NT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double lam = h->lam0;
+    std::vector<double> erange(L, 0.0);
+    for (int l = 0; l < L; ++l) {
+        double em = 0.0;
+        for (int n = 0; n < NT; ++n) em = std::max(em, std::fabs(h->eps_stage[(size_t)l * NT + n]));
+        erange[l] = widen * em;
+        lam += erange[l] * h->lam_l[l];
+    }
+    const double cap = (h->method == KR_PROP_CHEBY) ? 6.0 : 1.5;
+    const double tol = std::max(h->tol, 1e-17);
+    h->ptab_host.assign((size_t)NT * h->ptab_stride, 0.0);
+    std::vector<std::pair<double, std::vector<double>>> cache;
+    for (int n = 0; n < NT; ++n) {
+        const double full = std::fabs(h->dt_host[n]) * lam;
+        const int s = std::max(1, (int)std::ceil(full / cap));
+        const double th = std::max(full / s, 1e-300);
+        double *row = &h->ptab_host[(size_t)n * h->ptab_stride];
+        const std::vector<double> *hit = nullptr;
+        for (auto &c : cache) if (c.first == th) { hit = &c.second; break; }
+        if (!hit) {
+            std::vector<double> r(h->ptab_stride, 0.0);
+            const int d = (h->method == KR_PROP_CHEBY) ? cheby_row(th, tol, r.data()) : newton_row(th, tol, r.data());
+            r[0] = d; r[2] = th;
+            cache.emplace_back(th, std::move(r));
+            hit = &cache.back().second;
+        }
+        memcpy(row, hit->data(), h->ptab_stride * sizeof(double));
+        row[1] = s;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->ptab_d, h->ptab_host.data(), h->ptab_host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->erange_d, erange.data(), (size_t)L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // (erange is a local)
+    return KR_OK;
+}
+
 // ---- generic (multi-pass) sweeps -------------------------------------------------------------------
 static void gen_args(kr_handle *h, KrGenArgs &g) {
     memset(&g, 0, sizeof g);
@@ -985,6 +1120,7 @@ static void gen_args(kr_handle *h, KrGenArgs &g) {
     memcpy(g.thr, h->thr, sizeof g.thr);
     g.N = h->cfg.N; g.NT = h->cfg.NT; g.Kp = h->Kp; g.L = h->cfg.L; g.G = h->G;
     g.KTG = h->KTG; g.RP = h->RP; g.JQ = h->JQg; g.tiles = h->gen_tiles;
+    g.method = h->method; g.ptab = h->ptab_d; g.ptab_stride = h->ptab_stride; g.erange = nullptr; g.status = h->status_d;
 }
 
 static int launch_known_generic(kr_handle *h, const double *eps_dev, bool backward, const double2 *init, double2 *store, double2 *fin) {
@@ -994,6 +1130,7 @@ static int launch_known_generic(kr_handle *h, const double *eps_dev, bool backwa
     g.eps = eps_dev;
     g.init = init; g.store = store; g.fin = fin;
     g.dir = backward ? -1 : +1;
+    if (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON) { const int rc = build_poly_tables(h, eps_dev, 1.0); if (rc) return rc; }
     HIPCHK(h, kr_launch_generic(0, h->KTG, h->gen_tiles, h->gen_lds, h->stream, &g));
     return KR_OK;
 }
@@ -1019,6 +1156,11 @@ static int launch_update_stepped(kr_handle *h, const double *eps_guess_dev, doub
     const bool use_rccl = h->exchange == KR_EXCHANGE_RCCL && h->rccl_comm;
     const bool use_cb = h->exchange == KR_EXCHANGE_CALLBACK && h->cb;
     g.du_total = (use_rccl || use_cb) ? h->du_total_d : h->du_local_d;
+    if (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON) {
+        const int rc = build_poly_tables(h, eps_guess_dev, 5.0);
+        if (rc) return rc;
+        g.erange = h->erange_d;
+    }
     HIPCHK(h, hipMemcpyAsync(h->psiT_d, h->psi0_d, slab * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
     if (h->store_fw) HIPCHK(h, hipMemcpyAsync(h->Phi_d, h->psi0_d, slab * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->gint_d, 0, (size_t)L * sizeof(double), h->stream));
@@ -1190,6 +1332,9 @@ static int check_status(kr_handle *h) {
         // sticky until read (launches never clear it, so a failure inside a chain of *_dev calls is not lost)
         HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (st[1] == 5)
+            return fail(h, KR_ERR_UNSUPPORTED, "update sweep: at step %u an updated control left the range the %s propagator was initialised for (5 x the guess amplitude, transform_control_ranges); results of this call are invalid -- use prop_method = TAYLOR or a larger lambda_a",
+                        st[2], h->method == KR_PROP_CHEBY ? "Chebyshev" : "Newton");
         const char *what = st[1] == 4 ? "cross-rank sum of the taus (J_T_sm)"
                          : st[1] == 2 ? "inter-GPU exchange of the update sweep"
                          : st[1] == 3 ? "row-split all-gather (the R workgroups of a trajectory)"

@@ -186,3 +186,45 @@ def test_callback_exchange_two_ranks_vs_unsharded_oracle(oracle_c):
     eps_o, ga_o, psiT1_o, _, _ = oracle_c.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT)
     assert _rel(got[0][0], eps_o) < TOL_PULSE and _rel(got[0][1], ga_o) < 1e-9
     assert np.max(np.abs(np.concatenate([got[0][2], got[1][2]]) - psiT1_o)) < 1e-9
+
+
+@pytest.mark.parametrize("method", [capi.KR_PROP_CHEBY, capi.KR_PROP_NEWTON])
+def test_propagator_methods_vs_oracle(oracle_c, method):
+    """kr_config.prop_method (the reference's prop_method, /root/reference/src/optimize.jl:108,137-153): Chebyshev
+    (Hermitian generators; spectral range from the control range, widened 5x in the update sweep as transform_control_ranges
+    does, optimize.jl:238-244) and Newton interpolation at Leja points (any generator), against the oracle's exact expm at
+    the tolerances of the Taylor path."""
+    cases = [wl.dense_problem(12, 20, 5, 2, 601, 0.1, 5.0), wl.dense_problem(40, 10, 7, 1, 602, 0.05, 5.0),
+             wl.dense_problem(6, 15, 3, 3, 603, 0.1, 5.0)]
+    big = wl.dense_problem(10, 8, 4, 1, 604, 0.1, 50.0)
+    big["H0"] = big["H0"] * 30.0          # ||H dt|| ~ 3: sub-steps for Newton, a long Chebyshev series
+    cases.append(big)
+    rng = np.random.default_rng(9)
+    nonuni = wl.dense_problem(9, 12, 4, 2, 605, 0.1, 5.0)
+    nonuni["tlist"] = np.cumsum(np.r_[0.0, rng.uniform(0.05, 0.2, 12)])   # one table row per distinct dt
+    cases.append(nonuni)
+    for p in cases:
+        info = _check(oracle_c, p, prop_method=method)
+        assert info["generic_known"] == 1 and info["generic_update"] == 1
+    if method == capi.KR_PROP_NEWTON:     # non-Hermitian generator (a Liouvillian): Newton only
+        p = wl.liouvillian_problem(n_levels=4, NT=12, K=5, seed=606, dt=0.1, lam=5.0)
+        _check(oracle_c, p, prop_method=method)
+    else:
+        p = wl.dense_problem(8, 5, 2, 1, 607, 0.1, 1.0)
+        p["H0"] = p["H0"] + 0.01j * np.eye(8)
+        with pytest.raises(kr.KrotovHipError) as ei:
+            kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 2, prop_method=method)
+        assert "Hermitian" in str(ei.value)
+
+
+def test_polynomial_propagator_reports_a_control_that_leaves_its_range(oracle_c):
+    """Chebyshev / Newton are initialised for 5 x the guess amplitude; an update beyond that must be reported, not
+    propagated with a polynomial that no longer covers the spectrum."""
+    p = wl.dense_problem(8, 10, 3, 1, 610, 0.1, 1e-4)      # tiny lambda_a: a huge update
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 3, prop_method=capi.KR_PROP_CHEBY) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+        with pytest.raises(kr.KrotovHipError) as ei:
+            eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        assert ei.value.code == capi.KR_ERR_UNSUPPORTED and "left the range" in str(ei.value)
