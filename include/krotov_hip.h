@@ -112,6 +112,12 @@ typedef struct kr_config {
     int32_t n_devices;             /* > 1: ONE handle drives n_devices GPUs from this process (trajectories block-
                                       partitioned over them; rank/world must be 0/1); 0 or 1: `device` alone     */
     int32_t devices[8];            /* HIP device ordinals of the n_devices GPUs (the same ordinal may repeat)     */
+    /* non-linear controls, static part: H(eps) = H0 + sum_l f_l(eps_l) H_l with polynomials
+     * f_l(x) = sum_p control_poly[l][p] x^p.  The control derivative is then mu_l = f_l'(eps_l) H_l, evaluated at the GUESS
+     * value of the step as _eval_mu does (optimize.jl:268-272,337,345).  degree 0 / NULL = linear controls (f_l(x) = x).   */
+    int32_t control_poly_degree;   /* 0 (linear) or 1..7                                         */
+    int32_t pad_;
+    const double *control_poly;    /* [L][control_poly_degree + 1], or NULL                      */
     int32_t reserved[8];
 } kr_config;
 

@@ -42,6 +42,7 @@ class KrConfig(C.Structure):
         ("rank", C.c_int32), ("world", C.c_int32), ("K_global", C.c_int32),
         ("exchange", C.c_int32), ("prop_method", C.c_int32), ("max_workgroups", C.c_int32),
         ("n_devices", C.c_int32), ("devices", C.c_int32 * 8),
+        ("control_poly_degree", C.c_int32), ("pad_", C.c_int32), ("control_poly", C.c_void_p),
         ("reserved", C.c_int32 * 8),
     ]
 

@@ -185,6 +185,8 @@ struct KrGenArgs {
     // step propagator (kr_prop_method): per-step tables of the polynomial methods (kr_gen_propagate)
     int method, ptab_stride;
     const double *ptab;
+    const double *poly;        // non-linear controls: [L][poly_deg + 1] coefficients of f_l, or nullptr (f_l(x) = x)
+    int poly_deg;
     const double *erange;      // [L] control range the polynomial methods were initialised for (update sweep), or nullptr
     unsigned *status;
 };

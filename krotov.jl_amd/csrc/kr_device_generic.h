@@ -18,6 +18,22 @@
 #pragma once
 #include "kr_common.h"
 
+// non-linear controls: amplitude f_l(x) and derivative f_l'(x) of control l (Horner)
+__device__ __forceinline__ double kr_gen_f(const KrGenArgs &a, const int l, const double x) {
+    if (!a.poly) return x;
+    const double *cf = a.poly + (size_t)l * (a.poly_deg + 1);
+    double v = cf[a.poly_deg];
+    for (int p = a.poly_deg - 1; p >= 0; --p) v = fma(v, x, cf[p]);
+    return v;
+}
+__device__ __forceinline__ double kr_gen_fprime(const KrGenArgs &a, const int l, const double x) {
+    if (!a.poly) return 1.0;
+    const double *cf = a.poly + (size_t)l * (a.poly_deg + 1);
+    double v = a.poly_deg * cf[a.poly_deg];
+    for (int p = a.poly_deg - 1; p >= 1; --p) v = fma(v, x, p * cf[p]);
+    return v;
+}
+
 __device__ __forceinline__ void kr_gen_plan(const KrGenArgs &a, const double theta, int &s, int &m) {
     if (theta <= KR_THETA_MAX) {
         s = 1;
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(256) void kr_gen_known(const KrGenArgs a) {
         const double sdt = (a.dir > 0) ? a.dt[n] : -a.dt[n];
         double theta = a.nrm[(size_t)gen * (1 + L)];
         c[0] = 1.0;
-        for (int l = 0; l < L; ++l) { c[1 + l] = a.eps[(size_t)l * NT + n]; theta += fabs(c[1 + l]) * a.nrm[(size_t)gen * (1 + L) + 1 + l]; }
+        for (int l = 0; l < L; ++l) { c[1 + l] = kr_gen_f(a, l, a.eps[(size_t)l * NT + n]); theta += fabs(c[1 + l]) * a.nrm[(size_t)gen * (1 + L) + 1 + l]; }
         kr_gen_propagate<KTG>(a, Hb, 1 + L, c, theta * fabs(sdt), sdt, n, psi, y0, y1, y2, red);
         if (a.store) {
             const int slot = (a.dir > 0) ? (n + 1) : n;
@@ -269,11 +285,14 @@ __global__ __launch_bounds__(256) void kr_gen_form(const KrGenArgs a) {
     const double2 *Hb = a.H + (size_t)gen * a.gen_stride;
     double2 h = Hb[e];
     for (int l = 0; l < L; ++l) {
-        const double al = a.alpha[(size_t)l * NT + n], eg = a.eps[(size_t)l * NT + n], du = a.du_total[l];
+        const double al = a.alpha[(size_t)l * NT + n], eg = a.eps[(size_t)l * NT + n];
+        // mu_l = f_l'(eps_guess) H_l (the derivative is evaluated at the guess value, optimize.jl:337,345)
+        const double du = a.poly ? __dmul_rn(kr_gen_fprime(a, l, eg), a.du_total[l]) : a.du_total[l];
         const double en = __dadd_rn(eg, __dmul_rn(al, du));   // optimize.jl:355, no FMA contraction
         const double2 hl = Hb[(size_t)(1 + l) * nn + e];
-        h.x = fma(en, hl.x, h.x);
-        h.y = fma(en, hl.y, h.y);
+        const double amp = kr_gen_f(a, l, en);
+        h.x = fma(amp, hl.x, h.x);
+        h.y = fma(amp, hl.y, h.y);
         if (idx == 0) {
             // Chebyshev / Newton were initialised for |eps_l| <= erange[l] (guess range x 5): an update that leaves it would be
             // propagated with a polynomial that no longer covers the spectrum -- report instead of returning wrong states
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(256) void kr_gen_apply(const KrGenArgs a) {
     for (int e = threadIdx.x; e < tot; e += blockDim.x) psi[e] = a.state[tb + e];
     __syncthreads();
     double theta = a.nrm[(size_t)gen * (1 + L)];
-    for (int l = 0; l < L; ++l) theta += fabs(a.eps_new[(size_t)l * NT + n]) * a.nrm[(size_t)gen * (1 + L) + 1 + l];
+    for (int l = 0; l < L; ++l) theta += fabs(kr_gen_f(a, l, a.eps_new[(size_t)l * NT + n])) * a.nrm[(size_t)gen * (1 + L) + 1 + l];
     const double one = 1.0, dtn = a.dt[n];
     kr_gen_propagate<KTG>(a, a.Heps + (size_t)gen * N * N, 1, &one, theta * fabs(dtn), dtn, n, psi, y0, y1, y2, red);
     for (int e = threadIdx.x; e < tot; e += blockDim.x) {

@@ -100,6 +100,8 @@ struct kr_handle {
     int exchange = KR_EXCHANGE_AUTO;   // resolved at kr_create
     int method = KR_PROP_AUTO;         // kr_prop_method; Chebyshev / Newton run on the generic kernels
     double *ptab_d = nullptr, *erange_d = nullptr;
+    double *poly_d = nullptr;          // non-linear controls: [L][poly_deg + 1] coefficients of f_l (generic kernels), or nullptr
+    int poly_deg = 0;
     int ptab_stride = 0;
     double lam0 = 0.0;                 // max over generators of the norm bound of H0
     std::vector<double> lam_l;         // [L] the same for H_l
@@ -471,7 +473,10 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
     if (c.exchange < KR_EXCHANGE_AUTO || c.exchange > KR_EXCHANGE_CALLBACK) return fail(h, KR_ERR_INVALID, "kr_create: exchange = %d", c.exchange);
     if (c.prop_method < KR_PROP_AUTO || c.prop_method > KR_PROP_NEWTON) return fail(h, KR_ERR_INVALID, "kr_create: prop_method = %d", c.prop_method);
     h->method = c.prop_method;
-    const bool poly = (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON);   // these live in the generic kernels
+    const bool nonlinear = c.control_poly_degree > 0 && h->poly_deg > 0;
+    if (nonlinear && (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON))
+        return fail(h, KR_ERR_UNSUPPORTED, "non-linear controls with prop_method = CHEBY / NEWTON are not supported (use TAYLOR)");
+    const bool poly = (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON) || nonlinear;   // these live in the generic kernels
     int rc = (genv == 1 || poly) ? KR_ERR_UNSUPPORTED : make_plan_fast(h, tg, wg_gen, c.max_workgroups);
     h->fast_ok = (rc == KR_OK);
     if (rc != KR_OK && rc != KR_ERR_UNSUPPORTED) return rc;
@@ -553,7 +558,7 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d,
-                    h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d};
+                    h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected && !h->peers_in_process)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -651,6 +656,16 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
 #define CHK(call) do { hipError_t e2_ = (call); if (e2_ != hipSuccess) { fail(h, KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2_)); return bail(KR_ERR_HIP); } } while (0)
     CHK(hipSetDevice(dev));
     h->G = cfg->G;
+    h->cfg.control_poly = nullptr;
+    if (cfg->control_poly_degree != 0 || cfg->control_poly) {
+        if (cfg->control_poly_degree < 1 || cfg->control_poly_degree > 7 || !cfg->control_poly) {
+            fail(h, KR_ERR_INVALID, "kr_create: control_poly needs a degree in 1..7 and the coefficient array (got degree %d)", cfg->control_poly_degree);
+            return bail(KR_ERR_INVALID);
+        }
+        h->poly_deg = cfg->control_poly_degree;
+        CHK(dalloc(&h->poly_d, (size_t)cfg->L * (h->poly_deg + 1)));
+        CHK(hipMemcpy(h->poly_d, cfg->control_poly, (size_t)cfg->L * (h->poly_deg + 1) * sizeof(double), hipMemcpyHostToDevice));
+    }
     std::vector<int> wg_gen;
     rc = make_plan(h, cfg->traj_generator, wg_gen);
     if (rc != KR_OK) return bail(rc);
@@ -1120,6 +1135,7 @@ static void gen_args(kr_handle *h, KrGenArgs &g) {
     memcpy(g.thr, h->thr, sizeof g.thr);
     g.N = h->cfg.N; g.NT = h->cfg.NT; g.Kp = h->Kp; g.L = h->cfg.L; g.G = h->G;
     g.KTG = h->KTG; g.RP = h->RP; g.JQ = h->JQg; g.tiles = h->gen_tiles;
+    g.poly = h->poly_d; g.poly_deg = h->poly_deg;
     g.method = h->method; g.ptab = h->ptab_d; g.ptab_stride = h->ptab_stride; g.erange = nullptr; g.status = h->status_d;
 }
 

@@ -15,7 +15,8 @@ from . import _capi as capi
 
 class HipEngine:
     def __init__(self, H0, Hc, tlist, K, *, hc_present=None, traj_generator=None, store_fw=True, prop_tol=0.0,
-                 device=-1, rank=0, world=1, K_global=0, exchange=0, prop_method=0, max_workgroups=0, devices=None):
+                 device=-1, rank=0, world=1, K_global=0, exchange=0, prop_method=0, max_workgroups=0, devices=None,
+                 control_poly=None):
         """H0 (N,N) and Hc (L,N,N) for a generator shared by all trajectories, or H0 (G,N,N), Hc (G,L,N,N)
         with traj_generator[k] in 0..G-1 for per-trajectory generators (control_derivs[k][l],
         /root/reference/src/workspace.jl:74)."""
@@ -66,6 +67,13 @@ class HipEngine:
             for i, d in enumerate(devices):
                 cfg.devices[i] = int(d)
         self._cb = None
+        self._poly = None
+        if control_poly is not None:   # f_l(x) = sum_p control_poly[l][p] x^p  (non-linear controls, static part)
+            self._poly = np.ascontiguousarray(control_poly, np.float64)
+            if self._poly.ndim != 2 or self._poly.shape[0] != self.L or not 2 <= self._poly.shape[1] <= 8:
+                raise ValueError("control_poly must have shape (L, degree + 1) with degree 1..7")
+            cfg.control_poly_degree = self._poly.shape[1] - 1
+            cfg.control_poly = capi.ptr(self._poly)
         rc = lib.kr_create(C.byref(cfg), C.byref(self._h))
         if rc != capi.KR_OK:
             msg = lib.kr_last_error(None)

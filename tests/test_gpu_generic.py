@@ -228,3 +228,42 @@ def test_polynomial_propagator_reports_a_control_that_leaves_its_range(oracle_c)
         with pytest.raises(kr.KrotovHipError) as ei:
             eng.iteration(p["eps"], chiT, p["S"], p["lam"])
         assert ei.value.code == capi.KR_ERR_UNSUPPORTED and "left the range" in str(ei.value)
+
+
+def test_nonlinear_polynomial_controls():
+    """Non-linear controls, static part: H(eps) = H0 + sum_l f_l(eps_l) H_l with polynomial f_l; the
+    control derivative mu_l = f_l'(eps_l) H_l is evaluated at the GUESS value of the step, as _eval_mu does
+    (/root/reference/src/optimize.jl:268-272,337,345).  Against a serial restatement of optimize.jl:328-370 built on the
+    oracle's exact step propagator."""
+    import krotov_oracle as o
+    p = wl.dense_problem(10, 25, 6, 2, 620, 0.1, 0.5)
+    H0, Hc, tl, eps, S, lam, psi0, tgt = (p[k] for k in ("H0", "Hc", "tlist", "eps", "S", "lam", "psi0", "tgt"))
+    K, NT, L = 6, 25, 2
+    poly = np.array([[0.0, 1.0, 0.5, 0.0], [0.1, 0.8, 0.0, 2.0]])   # f_0 = x + x^2/2, f_1 = 0.1 + 0.8 x + 2 x^3
+    f = lambda l, x: sum(poly[l, q] * x ** q for q in range(4))
+    fp = lambda l, x: sum(q * poly[l, q] * x ** (q - 1) for q in range(1, 4))
+    amp = lambda e: np.array([f(l, e[l]) for l in range(L)])
+    with kr.HipEngine(H0, Hc, tl, K, control_poly=poly) as eng:
+        assert eng.info()["generic_update"] == 1
+        eng.set_initial_states(psi0)
+        psiT = eng.forward(eps)
+        psi = psi0.copy()
+        for n in range(NT):
+            psi = psi @ o.step_propagator(H0, Hc, amp(eps[:, n]), tl[n + 1] - tl[n]).T
+        assert np.max(np.abs(psiT - psi)) < 1e-11
+        _, _, chiT = wl.chi_and_JT("ss", psi, tgt)
+        eps_new, ga, psiT1 = eng.iteration(eps, chiT, S, lam)
+    X = np.empty((NT + 1, K, 10), complex)
+    X[NT] = chiT
+    for n in range(NT - 1, -1, -1):
+        U = o.step_propagator(H0, Hc, amp(eps[:, n]), tl[n + 1] - tl[n])
+        X[n] = X[n + 1] @ U.conj()      # chi <- U^dagger chi
+    psi, eps_o, ga_o = psi0.copy(), eps.copy(), np.zeros(L)
+    for n in range(NT):
+        for l in range(L):
+            du = sum(np.vdot(X[n, k], fp(l, eps[l, n]) * (Hc[l] @ psi[k])).imag for k in range(K))
+            eps_o[l, n] = eps[l, n] + S[l, n] / lam[l] * du
+            ga_o[l] += S[l, n] / lam[l] * du * du * (tl[n + 1] - tl[n])
+        psi = psi @ o.step_propagator(H0, Hc, amp(eps_o[:, n]), tl[n + 1] - tl[n]).T
+    assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < 1e-9 and np.max(np.abs(psiT1 - psi)) < 1e-10
+    assert np.max(np.abs(eps_new - eps)) > 1e-4
