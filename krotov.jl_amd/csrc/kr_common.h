@@ -22,6 +22,7 @@ struct KrSweepArgs {
     // the same matrices dense, row-major, zero-padded to 64 x 64: Hdense[g][m][row][col] (kr_device_mfma.h, NP = 64 only)
     const double2 *Hdense;
     size_t dense_stride;     // elements between two generators
+    int u_layout;            // 0: propagators packed for kr_sweep_apply (VALU); 1: as MFMA A operands for kr_mf_apply_sweep (kr_device_mfma.h)
     int gen_div;             // kr_sweep_apply: wg_gen is indexed by blockIdx.x / gen_div (apply tiles may be narrower than update tiles)
     const int *wg_gen;       // [P] generator of each workgroup's tile (nullptr: all 0)
     const double *nrm_dev;   // [G][1 + KR_LMAX_CAP] 2-norm bounds of H0, H_1..H_L per generator

@@ -435,10 +435,103 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     }
 }
 
+// =============================================================================================
+// Known-pulse sweep with precomputed propagators on the matrix cores: psi <- U_n psi, one MFMA round per step (the VALU
+// form is kr_sweep_apply, kr_device_prop.h).  packed(U psi) = Ur packed(psi) - Ui packed(-i psi), so with the operand
+// pairing of kr_mf_multi (first operand set times packed(-i w), second times packed(w)) the A operands are {-Ui, Ur}.
+// kr_expm_mfma64 writes them in exactly the order the lanes read them (KrSweepArgs::u_layout = 1):
+//      Umf[n][wave][slot][lane] = {-Ui, Ur} of U_n[16 wave + 4 blk + f0][4 ((4 wave + slot) & 15) + f2]      (64 KB per step)
+// so a step's operands are 16 coalesced 16-byte loads per lane, requested one step ahead.
+// =============================================================================================
+template <int TILES>
+__global__ __launch_bounds__(256, 1) void kr_mf_apply_sweep(const KrSweepArgs a) {
+    constexpr int KT = 2 * TILES, TW = KR_MF_TW, NW = 4, CH = KT;
+    __shared__ __attribute__((aligned(16))) double2 sx[2][TILES][TW];
+    const int tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f0 = lane & 3, blk = (lane >> 2) & 3, f2 = lane >> 4;
+    const int drow = 16 * wave + 4 * blk + f2, dt = f0 >> 1, dc = f0 & 1;
+    const int boff = f2 * 4 + f0, kb0 = 4 * wave, doff = drow * 4 + f0, zoff = drow * 4 + (f0 ^ 1);
+    const double zs = dc ? 1.0 : -1.0;
+    const bool memwave = (wave == NW - 1);
+    const int N = a.N, NT = a.NT;
+    const size_t slab = (size_t)a.Kp * N, tile_base = (size_t)wg * KT * N;
+    const int tile_elems = KT * N;
+    const bool row_ok = drow < N;
+    const double2 *__restrict__ Umf = a.U + (size_t)(a.wg_gen ? a.wg_gen[blockIdx.x / (a.gen_div > 0 ? a.gen_div : 1)] : 0) * NT * 4096;
+
+    int m_pos[CH];
+    bool m_ok[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int e = lane + 64 * c;
+        m_ok[c] = e < tile_elems;
+        const int tq = m_ok[c] ? e / N : 0, i = m_ok[c] ? e % N : 0;
+        m_pos[c] = (tq >> 1) * TW + i * 4 + 2 * (tq & 1);
+    }
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        double v = 0.0;
+        if (row_ok) v = ((const double *)a.init)[(tile_base + (size_t)(2 * t + dt) * N + drow) * 2 + dc];
+        kr_mf_put(sx[0][t], doff, zoff, zs, v);
+    }
+    if (memwave && a.store) {
+        const int slot0 = (a.dir > 0) ? 0 : NT;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (m_ok[c]) a.store[(size_t)slot0 * slab + tile_base + lane + 64 * c] = a.init[tile_base + lane + 64 * c];
+    }
+    // A operands of the first step
+    double2 un[16];
+    {
+        const int n0 = (a.dir > 0) ? 0 : (NT - 1);
+        const double2 *U = Umf + (size_t)n0 * 4096 + (size_t)wave * 1024 + lane;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) un[sl] = U[sl * 64];
+    }
+    __syncthreads();
+    int cur = 0;
+    double psi[TILES];
+    for (int step = 0; step < NT; ++step) {
+        const int n = (a.dir > 0) ? step : (NT - 1 - step);
+        double Ar[16], Ai[16];
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) { Ar[sl] = un[sl].x; Ai[sl] = un[sl].y; }
+        if (step + 1 < NT) {   // operands of the next step: they land while this step's round runs
+            const int n1 = (a.dir > 0) ? (step + 1) : (NT - 2 - step);
+            const double2 *U = Umf + (size_t)n1 * 4096 + (size_t)wave * 1024 + lane;
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) un[sl] = U[sl * 64];
+        }
+        kr_mf_apply<TILES>(Ar, Ai, &sx[cur][0][0], boff, kb0, psi);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) kr_mf_put(sx[cur ^ 1][t], doff, zoff, zs, psi[t]);
+        __syncthreads();
+        cur ^= 1;
+        if (memwave && a.store) {
+            const int slot = (a.dir > 0) ? (n + 1) : n;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (m_ok[c]) a.store[(size_t)slot * slab + tile_base + lane + 64 * c] = make_double2((&sx[cur][0][0])[m_pos[c]].y, (&sx[cur][0][0])[m_pos[c] + 1].y);
+        }
+    }
+    if (a.fin && memwave) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (m_ok[c]) a.fin[tile_base + lane + 64 * c] = make_double2((&sx[cur][0][0])[m_pos[c]].y, (&sx[cur][0][0])[m_pos[c] + 1].y);
+    }
+}
+
 // kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (as kr_launch_np); tiles = trajectories per workgroup / 2.
 // One translation unit per LMAX (kr_mf64_l2.hip, kr_mf64_l4.hip).
 template <int LM>
 static hipError_t kr_launch_mfma64(int tiles, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
+    if (kind == 3) {   // known-pulse sweep on precomputed propagators (LM-independent: instantiated in the LM = 2 unit only)
+        if constexpr (LM == 2) {
+            if (tiles == 1) { kr_launch_kernel((kr_mf_apply_sweep<1>), grid, 256, 0, s, *a); return hipGetLastError(); }
+            if (tiles == 2) { kr_launch_kernel((kr_mf_apply_sweep<2>), grid, 256, 0, s, *a); return hipGetLastError(); }
+        }
+        return hipErrorInvalidValue;
+    }
     if ((kind & 15) != 1) return hipErrorInvalidValue;
     const int v = ((kind >> 4) & 1) | (((kind >> 6) & 1) << 1) | (((kind >> 5) & 1) << 2);   // SCHED | HERM << 1 | CAL << 2
 #define KR_CASE_M(TL)                                                                                              \

@@ -320,8 +320,18 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
         __syncthreads();
         cur ^= 1;
     }
-    // U_n -> thread-major pack of the apply kernel: Upack[jj * 256 + i*4 + jq] = U[i][jq*16 + jj]
+    // U_n -> the consumer's operand order.  u_layout = 1 (kr_mf_apply_sweep, kr_device_mfma.h): MFMA A operands
+    //   Umf[wave][slot][lane] = {-Ui, Ur} of U[16 wave + 4 blk + f0][4 ((4 wave + slot) & 15) + f2],  lane = (f0, blk, f2)
     double2 *Un = a.U + ((size_t)gx.gen * NT + n) * NP * NP;
+    if (a.u_layout == 1) {
+        for (int e = tid; e < 4096; e += 256) {
+            const int l = e & 63, sl = (e >> 6) & 15, wv = e >> 10;
+            const int r = 16 * wv + 4 * ((l >> 2) & 3) + (l & 3), cc = 4 * ((4 * wv + sl) & 15) + (l >> 4);
+            Un[e] = make_double2(-KR_YI(cur)[r * KR_YS + cc], KR_YR(cur)[r * KR_YS + cc]);
+        }
+        return;
+    }
+    // u_layout = 0: thread-major pack of kr_sweep_apply: Upack[jj * 256 + i*4 + jq] = U[i][jq*16 + jj]
     for (int t2 = tid; t2 < RT_A; t2 += 256) {   // consumer thread t2 = (i, jq)
         const int i = t2 / JQ_A, jq = t2 % JQ_A;
 #pragma unroll

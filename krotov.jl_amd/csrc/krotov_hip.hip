@@ -1219,8 +1219,25 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         if (rc) return rc;
         HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 0, h->P, h->stream, &a));
     } else if (h->precomp) {
-        // all N_T step propagators in parallel, then one matvec round per step
-        HIPCHK(h, h->launch(h->LMAXv, h->KT, 2, h->cfg.NT * h->G, h->stream, &a));
+        // all N_T step propagators in parallel, then one matvec round per step.  N = 64: both on the matrix cores
+        // (kr_expm_mfma64 writes the propagators as MFMA A operands, kr_mf_apply_sweep applies them, two trajectories per
+        // 4-column tile); KROTOV_HIP_MFMA_APPLY=0 keeps the vector apply kernel.
+        // Measured (us per step incl. the build): K = 1024: 2.51 -> 2.22, K = 512: 1.56 -> 1.44, but K = 256 (one trajectory
+        // per workgroup in the vector kernel): 1.14 -> 1.26 -- both forms are bound by streaming the 64 KB of U_n into every
+        // CU each step, so the matrix cores only pay where the vector kernel is VALU-bound (several trajectories per team).
+        const int mfa = env_int("KROTOV_HIP_MFMA_APPLY", -1);
+        const bool mf_apply = h->NP == 64 && h->use_mfma && (mfa == 1 || (mfa == -1 && h->KT >= 2)) && (h->Kp % 2 == 0) &&
+                              (h->G == 1 || h->KT % 2 == 0);
+        a.u_layout = mf_apply ? 1 : 0;
+        HIPCHK(h, h->launch(h->LMAXv, std::min(h->KT, 4), 2, h->cfg.NT * h->G, h->stream, &a));
+        if (mf_apply) {
+            int kt_a = (h->KT % 2 == 0) ? std::min(h->KT, 4) : 2;
+            const int want_a = env_int("KROTOV_HIP_MFMA_APPLY_KT", 0);   // (tuning knob: 2 or 4 trajectories per workgroup)
+            if ((want_a == 2 || want_a == 4) && h->Kp % want_a == 0 && (h->G == 1 || h->KT % want_a == 0 || want_a % h->KT == 0) && (h->G == 1 || want_a <= h->KT)) kt_a = want_a;
+            a.gen_div = std::max(1, h->KT / kt_a);
+            HIPCHK(h, kr_launch_mf64(2, kt_a / 2, 3, h->Kp / kt_a, h->stream, &a));
+            return ev_mark(h, which_ev, true);
+        }
         // The apply sweep is bound by streaming U_n (NP^2 * 16 B per workgroup per step) from L2: with a shared
         // generator, wider tiles (more trajectories per workgroup, fewer workgroups) cut that traffic.
         int kt_apply = std::min(h->KT, 4);   // (KT = 8 exists only for the matrix-core update sweep)
