@@ -284,15 +284,15 @@ def main():
         # command; bench.py itself does not run under rocprofv3).  Only quoted for the configuration it was taken on.
         traffic, traffic_src = None, None
         try:
-            for name in ("r02_traffic.json", "r01_traffic.json"):
+            for name in ("r02_traffic_all.json", "r01_traffic.json"):
                 path = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(path):
                     continue
                 with open(path) as f:
                     tj = json.load(f)
-                if tj.get("config") == args.config and world == 1:
-                    traffic, traffic_src = tj["traffic_bytes_per_launch"], tj["source"]
-                    break
+                for entry in (tj if isinstance(tj, list) else [tj]):
+                    if entry.get("config") == args.config and world == 1 and args.traj == 0 and traffic is None:
+                        traffic, traffic_src = entry["traffic_bytes_per_launch"], entry["source"]
         except (OSError, ValueError, KeyError):
             pass
         bytes_upd = K_local * NT * 32.0 * N
