@@ -1310,6 +1310,17 @@ static int calibrate_exchange(kr_handle *h) {
     if (fixed != -2) { h->poll_delay = fixed; return KR_OK; }
     // (N > 64: a step holds ~9 memory round trips of which the exchange is one: not worth 0.2 s of calibration)
     if (h->gen_update || h->P < 64 || h->NP > 64 || !env_int("KROTOV_HIP_CALIBRATE", 1)) return KR_OK;
+    // One measurement per process and launch shape: later handles of the same shape reuse it (the schedule then no longer
+    // depends on the timing noise of every single kr_create, and the ~30 calibration sweeps are paid once).
+    // KROTOV_HIP_CALIBRATE_CACHE=0 measures every time.
+    static std::mutex cal_mtx;
+    static std::vector<std::pair<std::vector<int>, int>> cal_cache;
+    const std::vector<int> key = {h->device, h->NP, h->LMAXv, h->KT, h->P, h->herm ? 1 : 0, h->mfma_sweep ? 1 : 0, h->cfg.L, h->cfg.N};
+    const bool use_cache = env_int("KROTOV_HIP_CALIBRATE_CACHE", 1) != 0;
+    if (use_cache) {
+        std::lock_guard<std::mutex> g(cal_mtx);
+        for (auto &c : cal_cache) if (c.first == key) { h->poll_delay = c.second; return KR_OK; }
+    }
     const int L = h->cfg.L, NT = h->cfg.NT, steps = std::min(NT, 256);
     const size_t slice = (size_t)h->Kp * h->cfg.N;
     const unsigned epoch_saved = h->epoch_base;   // calibration launches must not advance the tag sequence the ranks share
@@ -1346,6 +1357,10 @@ static int calibrate_exchange(kr_handle *h) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     h->poll_delay = best_delay;
+    if (rc == KR_OK && use_cache) {
+        std::lock_guard<std::mutex> g(cal_mtx);
+        cal_cache.emplace_back(key, best_delay);
+    }
     // The number of calibration launches depends on timing (refinement only for best_delay > 0), so ranks would leave
     // this function with different epoch bases and their inter-GPU tags would never match.  Restore the base and wipe the
     // calibration tags from the intra-GPU mailbox (calibration runs with world = 1: xmail was never written).
