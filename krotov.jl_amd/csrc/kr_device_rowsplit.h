@@ -157,6 +157,10 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
 // blocks instead of 1 + L (the pass is bound by the CU's L1 fill rate: 256 KB per block at N = 256, NR = 64).  Every
 // KR_RS_REFRESH-th step rebuilds Heps from H0, which bounds the accumulated rounding (<= 32 additions of 1 ulp each).
 #define KR_RS_REFRESH 32
+#ifndef KR_RS_SCHED
+#define KR_RS_SCHED 1   // exchange schedule of the row-split update sweep (kr_exchange): 1 = publisher wave + delayed poll (a.poll_delay x 128
+                        // cycles; measured at C5, us per step: schedule 0 42.6; schedule 1 with delay 0 / 4 / 8 / 12 / 16 / 24: 41.5 / 41.2 / 41.1 / 40.9 / 40.9 / 40.9)
+#endif
 template <int NP, int NR, int LMAX, int MODE, bool INC = false>
 __device__ __forceinline__ void kr_rs_stream(const __amdgpu_buffer_rsrc_t rsrc, const int rb, const int L, const double (&e)[LMAX],
                                              double (&Er)[KrGeomR<NP, NR, LMAX>::JSR], double (&Ei)[KrGeomR<NP, NR, LMAX>::JSR],
@@ -367,7 +371,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
                 if (l < L && ((gx.present >> l) & 1u)) part[l] = cr * oi[1 + l] - ci * orr[1 + l];
             }
             if (n + 1 < NT && row_ok) { const double2 c = a.X[(size_t)(n + 1) * slab + kbase + row]; cr = c.x; ci = c.y; }
-            if (!kr_exchange<LMAX, NR>(a, n, wg, owner, il, part, du, spart, stot)) return;
+            if (!kr_exchange<LMAX, NR, KR_RS_SCHED>(a, n, wg, owner, il, part, du, spart, stot)) return;
             KR_STAMP(tX)
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) {

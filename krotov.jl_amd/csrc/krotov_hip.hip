@@ -998,6 +998,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.debug = h->debug_on ? h->debug_d : nullptr;
     a.mail = h->mail_d;
     a.poll_delay = h->poll_delay;
+    if (h->rowsplit && h->poll_delay < 0) a.poll_delay = env_int("KROTOV_HIP_RS_POLL_DELAY", 12);   // row-split update sweep: kr_exchange<.., SCHED = 1> (KR_RS_SCHED)
     a.xpoll_delay = env_int("KROTOV_HIP_XPOLL_DELAY", 0);
     // row-split all-gather: polling starts 9 x 128 cycles (0.48 us) after the block was handed to the publishing wave;
     // measured at C5 (forward sweep, us per step): 0 -> 32.4, 4 -> 31.5, 8 -> 30.6, 10 -> 30.4, 12 -> 31.0, 16 -> 32.8, 20 -> 34.7
