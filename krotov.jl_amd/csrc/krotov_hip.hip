@@ -310,10 +310,11 @@ struct KrRccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
+static KrRccl g_rccl;
 static KrRccl *kr_rccl() {
-    static KrRccl r;
+    KrRccl &r = g_rccl;
     static std::once_flag once;
-    std::call_once(once, [] {
+    std::call_once(once, [&r] {
         // One RCCL per process: a second copy (PyTorch-ROCm bundles its own librccl.so, which its libtorch_hip.so requests
         // under that name) ends in a double free at exit.  KROTOV_HIP_RCCL_LIB names the copy to use (the Python binding
         // points it at PyTorch's file); otherwise whatever is mapped already, then the system library.
@@ -321,8 +322,8 @@ static KrRccl *kr_rccl() {
         const char *names[] = {(envp && *envp) ? envp : "librccl.so", "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         for (const char *n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (!r.lib) { r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
-#define KR_SYM(field, name) r.field = (decltype(r.field))dlsym(r.lib, name); if (!r.field) r.why = std::string("librccl lacks ") + name;
+        if (!r.lib) { const char *de = dlerror(); r.why = std::string("librccl could not be loaded: ") + (de ? de : "not found"); return; }
+#define KR_SYM(field, name) r.field = (decltype(r.field))dlsym(r.lib, name); if (!r.field && r.why.empty()) r.why = std::string("librccl lacks the symbol ") + name;
         KR_SYM(GetUniqueId, "ncclGetUniqueId") KR_SYM(CommInitRank, "ncclCommInitRank") KR_SYM(CommInitAll, "ncclCommInitAll")
         KR_SYM(CommDestroy, "ncclCommDestroy") KR_SYM(AllReduce, "ncclAllReduce") KR_SYM(GroupStart, "ncclGroupStart")
         KR_SYM(GroupEnd, "ncclGroupEnd") KR_SYM(GetErrorString, "ncclGetErrorString")
@@ -330,7 +331,7 @@ static KrRccl *kr_rccl() {
     });
     return r.why.empty() ? &r : nullptr;
 }
-static const char *kr_rccl_why() { (void)kr_rccl(); static KrRccl *dummy = nullptr; (void)dummy; return "librccl could not be loaded (dlopen)"; }
+static const char *kr_rccl_why() { (void)kr_rccl(); return g_rccl.why.empty() ? "librccl unavailable" : g_rccl.why.c_str(); }
 
 // ---- plan -------------------------------------------------------------------------------------
 static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen, int maxwg_cfg) {
