@@ -154,58 +154,48 @@ __global__ __launch_bounds__((KrApplyGeom<NP>::THREADS), (KrApplyGeom<NP>::THREA
         for (int c = 0; c < CH; ++c)
             if (m_tq[c] >= 0) a.store[(size_t)slot0 * slab + tile_base + lane + 64 * c] = a.init[tile_base + lane + 64 * c];
     }
-    // Propagator slices: two steps in flight (ua, ub) next to the one being used (Ur, Ui).  With one step in flight a step took
-    // latency + transfer of 64 KB per CU (~2000 cycles at NP = 64 against ~300 of arithmetic); the second buffer leaves
-    // the transfer.
-    double2 ua[JS], ub[JS];
+    // propagator slice of the first step
+    double2 un[JS];
     {
         const int n0 = (a.dir > 0) ? 0 : (NT - 1);
         const double2 *U = Upack + (size_t)n0 * NP * NP;
 #pragma unroll
-        for (int jj = 0; jj < JS; ++jj) ua[jj] = U[(size_t)jj * RT + tt];
-        if (NT > 1) {
-            const int n1 = (a.dir > 0) ? 1 : (NT - 2);
-            const double2 *U1 = Upack + (size_t)n1 * NP * NP;
-#pragma unroll
-            for (int jj = 0; jj < JS; ++jj) ub[jj] = U1[(size_t)jj * RT + tt];
-        }
+        for (int jj = 0; jj < JS; ++jj) un[jj] = U[(size_t)jj * RT + tt];
     }
     __syncthreads();
 
     int cur = 0;
-#define KR_APPLY_STEP(step_, un_)                                                                              \
-    {                                                                                                          \
-        const int n = (a.dir > 0) ? (step_) : (NT - 1 - (step_));                                              \
-        double Ur[JS], Ui[JS];                                                                                 \
-        _Pragma("unroll") for (int jj = 0; jj < JS; ++jj) { Ur[jj] = un_[jj].x; Ui[jj] = un_[jj].y; }          \
-        if ((step_) + 2 < NT) { /* slice of the step after next */                                             \
-            const int n2 = (a.dir > 0) ? ((step_) + 2) : (NT - 3 - (step_));                                   \
-            const double2 *U = Upack + (size_t)n2 * NP * NP;                                                   \
-            _Pragma("unroll") for (int jj = 0; jj < JS; ++jj) un_[jj] = U[(size_t)jj * RT + tt];               \
-        }                                                                                                      \
-        _Pragma("unroll") for (int q = 0; q < KT; ++q) {                                                       \
-            const int tq = q * SG + team;                                                                      \
-            double sr, si;                                                                                     \
-            kr_row_dot<JS, JQ>(Ur, Ui, &sx[cur][tq][xoff], sr, si);                                            \
-            if (writer) sx[cur ^ 1][tq][pi_] = make_double2(sr, si);                                           \
-        }                                                                                                      \
-        __syncthreads();                                                                                       \
-        cur ^= 1;                                                                                              \
-        if (memwave && a.store) {                                                                              \
-            const int slot = (a.dir > 0) ? (n + 1) : n;                                                        \
-            _Pragma("unroll") for (int c = 0; c < CH; ++c) {                                                   \
-                if (m_tq[c] >= 0) {                                                                            \
-                    const int ii = m_i[c];                                                                     \
-                    a.store[(size_t)slot * slab + tile_base + lane + 64 * c] = sx[cur][m_tq[c]][ii + ii / JS]; \
-                }                                                                                              \
-            }                                                                                                  \
-        }                                                                                                      \
+    for (int step = 0; step < NT; ++step) {
+        const int n = (a.dir > 0) ? step : (NT - 1 - step);
+        double Ur[JS], Ui[JS];
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) { Ur[jj] = un[jj].x; Ui[jj] = un[jj].y; }
+        if (step + 1 < NT) {  // slice of the next step: lands while this step's round runs
+            const int n1 = (a.dir > 0) ? (step + 1) : (NT - 2 - step);
+            const double2 *U = Upack + (size_t)n1 * NP * NP;
+#pragma unroll
+            for (int jj = 0; jj < JS; ++jj) un[jj] = U[(size_t)jj * RT + tt];
+        }
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+            const int tq = q * SG + team;
+            double sr, si;
+            kr_row_dot<JS, JQ>(Ur, Ui, &sx[cur][tq][xoff], sr, si);
+            if (writer) sx[cur ^ 1][tq][pi_] = make_double2(sr, si);
+        }
+        __syncthreads();
+        cur ^= 1;
+        if (memwave && a.store) {
+            const int slot = (a.dir > 0) ? (n + 1) : n;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (m_tq[c] >= 0) {
+                    const int ii = m_i[c];
+                    a.store[(size_t)slot * slab + tile_base + lane + 64 * c] = sx[cur][m_tq[c]][ii + ii / JS];
+                }
+            }
+        }
     }
-    for (int step = 0; step < NT; step += 2) {
-        KR_APPLY_STEP(step, ua)
-        if (step + 1 < NT) KR_APPLY_STEP(step + 1, ub)
-    }
-#undef KR_APPLY_STEP
     if (a.fin && memwave) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
