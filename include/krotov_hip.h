@@ -180,6 +180,9 @@ int kr_enable_timing(kr_handle *h, int on);
  * update sweep per phase {matvec+dot, exchange, Taylor, store} and the sweep's length in 100 MHz
  * ticks; out: 8 x uint64.  Zero when stamps are off.                                              */
 int kr_debug_stamps(kr_handle *h, unsigned long long *out);
+/* Diagnostic builds of the library only (-DKR_ARRIVALS): per workgroup {publish, end of window work, completion, poll passes}
+ * of two exchanges in the middle of the last update sweep, 100 MHz ticks; zeros otherwise.  words <= 8192. */
+int kr_debug_arrivals(kr_handle *h, unsigned long long *out, int words);
 
 /* Per-step exchange through RCCL (KR_EXCHANGE_RCCL): rank 0 makes a unique id, the host side broadcasts it, every
  * rank calls kr_rccl_init (collective).  librccl is loaded at run time (dlopen): no link-time dependency.

@@ -23,7 +23,7 @@ EXPORTS = [
     "kr_set_initial_states", "kr_set_target_states", "kr_forward", "kr_backward",
     "kr_update_forward", "kr_iteration", "kr_set_update_params", "kr_forward_dev",
     "kr_iteration_functional_dev", "kr_final_states", "kr_taus", "kr_g_a_int", "kr_synchronize",
-    "kr_read_storage", "kr_get_info", "kr_get_timings", "kr_enable_timing", "kr_debug_stamps",
+    "kr_read_storage", "kr_get_info", "kr_get_timings", "kr_enable_timing", "kr_debug_stamps", "kr_debug_arrivals",
     "kr_ipc_handle_size", "kr_ipc_export", "kr_ipc_connect",
     "kr_rccl_unique_id_size", "kr_rccl_get_unique_id", "kr_rccl_init", "kr_set_exchange_callback",
 ]

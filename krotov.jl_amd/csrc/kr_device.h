@@ -291,44 +291,46 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 // =============================================================================================
 // Per-step exchange of the L partial sums between the P workgroups of this GPU (and, for
 // world > 1, between GPUs through peer mailboxes over xGMI).  One hop, all-to-all: every
-// workgroup publishes 2L eight-byte granules {tag | half of a double} with agent-scope atomic
-// stores (write-through), wave 0 of every workgroup polls all P slots with agent-scope loads
+// workgroup publishes its L partial sums (8-byte doubles, see ONE-BIT validity below) with write-through
+// stores, wave 0 of every workgroup polls all P slots with loads that bypass the vector L1 (sc1)
 // and sums them in slot order, so every workgroup of every GPU obtains the bitwise identical
-// total.  Slots are double-buffered by step parity; tags increase monotonically over the life of
-// the handle, so nothing needs clearing between launches.  Spins are bounded.
+// total.  Slots are double-buffered by step parity.  Spins are bounded.
 // Wave 0 issues NO other vector-memory operation in the update kernel (state loads/stores belong
 // to the last wave): vmcnt retires in order and counts loads and stores together, so an HBM load or
 // a store acknowledgement queued in front of the poll sits on the critical path of every step.
 // Two schedules (template parameter SCHED; chosen per handle by calibrate_exchange in krotov_hip.hip):
-//   0    wave 0 publishes, then polls: its first pass also waits for the store's acknowledgement
-//        (1.2-1.9 us at P = 256), the second one (0.75 us) finds all tags;
+//   0    wave 0 publishes, does its share of the window work, then polls;
 //   1    wave 1 publishes (asm store, never waited for), wave 0 sleeps a.poll_delay x 128 cycles and
-//        then polls: with the right delay its FIRST pass finds all tags (C3: 7.0 -> 6.65 us/step);
-//        polling at once instead is slower than the first schedule (the stores become visible later
-//        under 256 polling workgroups).
+//        then polls.
 // Returns false when the exchange was aborted (status[0] set).
+// Where the time goes (tools/exchange_arrivals.py on a -DKR_ARRIVALS build, C3, P = 256): the workgroups publish within
+// 1.1-1.2 us of each other (median 0.3-0.45 us after the first; whole XCDs lag, and a late workgroup stays late: it still
+// does its 0.84 us of window work before it polls, while the others are done with theirs and complete 0.7-1.0 us after
+// the LAST publish); a workgroup completes 1.65 us (median) after its own publish; poll passes: 1 (median), 2 (max).
 // =============================================================================================
-// Mailbox slot = 2*LMAX granules, packed (32 B for LMAX = 2).  Measured at P = 256 (C3): 32-B slots 8.0k cycles
-// per exchange, 64-B 8.45k, 128-B 10.2k, granule-major (SoA, 16 writers per line) 10.3k: the cost grows with
-// the number of 128-B lines a poll pass touches and with the number of workgroups writing one line.
+// ONE-BIT validity (round 2; before: slot = 2*LMAX granules {tag32 | half of a double}, 32 B for LMAX = 2).  A slot is written by
+// one wave only, in step order, and a reader that has completed step n - 2 has
+// seen the slot's value of step n - 2 (same buffer: parity of n), so at step n it can only find that value or the new one --
+// one bit tells them apart.  The bit is the mantissa LSB of each partial sum, forced to the phase ((n >> 1) & 1) ^ 1 (the
+// mailbox is zeroed in front of every launch, so the first use of either buffer finds invalid slots): every 8-byte double
+// validates itself, a slot is LMAX doubles (16 B for LMAX = 2), a poll pass moves half
+// the bytes (tools/ubench/exchange.hip variant 11, P = 256: 1.51 against 1.87-2.12 us per exchange; same-box A/B of the update
+// sweep, us per step: C3 5.97 -> 5.86, C4 11.40 -> 11.12, K = 512 7.53 -> 7.32, C5 40.9 -> 40.3).  Every workgroup reads the
+// same slots -- its own included -- so all of them still form bitwise identical totals; the forced bit moves a partial sum by
+// at most one ulp.  The mailbox between GPUs (xmail, 8 slots) keeps its 32-bit tags: nothing zeroes it between launches.
+// (Slot width, measured at P = 256 with the tagged granules: 32-B slots 8.0k cycles per exchange, 64-B 8.45k, 128-B 10.2k,
+// granule-major 10.3k: the cost grows with the number of 128-B lines a poll pass touches.)
 #ifndef KR_SLOT_GRANULES
-#define KR_SLOT_GRANULES (2 * LMAX)
+#define KR_SLOT_GRANULES (LMAX)
 #endif
 #ifndef KR_POLL_SLEEP
 #define KR_POLL_SLEEP 0  // measured at P = 256: 0 -> 7.48 ms per update sweep, 1 -> 7.55, 4 -> 7.60, 16 -> 7.78
 #endif
 #define KR_POLL_CHUNKS 4  // slots per lane gathered with all loads in flight at once (P <= 256 in one go)
-// One poll pass with 16-byte loads: lane reads up to KR_POLL_CHUNKS slots (slot = LMAX 16-byte words {lo32, tag, hi32,
-// tag}, i.e. two self-validating 8-byte granules per word, so tearing between the halves of a word is harmless) with loads
-// that bypass the vector L1 (sc1).  All loads of a pass and their wait are ONE asm block: the compiler does not count asm
-// loads in vmcnt, so nothing may touch the results before the block ends.  Used by the row-split all-gather
-// (kr_device_rowsplit.h; C5 known-pulse sweeps 37.9 -> 34.3 us per step).  In isolation (tools/ubench/exchange.hip,
-// P = 256) this form also makes the per-step exchange faster (8-byte loads 2.70 us, 16-byte buffer loads emitted by the
-// compiler 2.29, this form 1.55-1.96; floor = one store->load round trip through memory, 1.35), but inside
-// kr_sweep_update it does not (same-box A/B at C3: 7.15-7.19 against 7.19-7.28 us per step; C2, P = 8: 4.14 against
-// 4.45): there the exchange is bound by the time the 256 partial stores take to become visible (first pass, which also
-// waits for the publishing store's acknowledgement, 1.2-1.9 us; later passes 0.75 us), so kr_exchange keeps its 8-byte
-// loads.  What does help there is an uncached (MTYPE UC) mailbox allocation: see alloc_mailbox in krotov_hip.hip.
+// KrPoll: one pass of the ROW-SPLIT ALL-GATHER (kr_device_rowsplit.h; elements = 16-byte words {lo32, tag, hi32, tag}, i.e. two
+// self-validating 8-byte granules per word, so tearing between the halves of a word is harmless) with 16-byte loads that bypass
+// the vector L1 (sc1).  All loads of a pass and their wait are ONE asm block: the compiler does not count asm loads in vmcnt,
+// so nothing may touch the results before the block ends (C5 known-pulse sweeps 37.9 -> 34.3 us per step).
 typedef unsigned int kr_v4u __attribute__((ext_vector_type(4)));
 #define KR_PL(o, p, off) "global_load_dwordx4 %" #o ", %" #p ", off offset:" #off " sc1\n\t"
 template <int LMAX> struct KrPoll;
@@ -351,45 +353,85 @@ template <> struct KrPoll<2> {
     }
 };
 
-// One wave gathers all P slots of buffer `par` until every slot carries `tag` (8-byte loads, all loads of a pass in
-// flight); tot = sum over the slots, same order as in kr_exchange.  Bounded; false = gave up (the caller's wave 0 flags it).
+// One poll pass over all P slots of buffer `par`: lane handles slots lane, lane + 64, ...; the loads of (up to) 4 x 64 slots
+// and their wait are ONE asm block of 16-byte sc1 loads (KrPoll above: the compiler neither counts nor reorders them).
+// tot = per-lane partial of the sum (slot order fixed), returns whether every slot of this lane carried `phase`.
+// Addressing: scalar base (buffer of this step) + ONE 32-bit lane offset + immediate chunk offsets, so that the poll keeps one
+// VGPR of addresses live instead of four 64-bit pointers (kr_sweep_update's HERM variant sits at the 256-VGPR limit).  No clamp
+// for the lanes past P: the mailbox is allocated with a tail of 64 slots (krotov_hip.hip), what they read is masked out.
+#define KR_PLS(o, v, sb, off) "global_load_dwordx4 %" #o ", %" #v ", %" #sb " offset:" #off " sc1\n\t"
+template <int LMAX> struct KrPollLsb;
+template <> struct KrPollLsb<2> {   // slot = one 16-byte word {d0, d1}; 64 slots = 1 KB
+    static constexpr int WORDS = 1;
+    static __device__ __forceinline__ void pass(const unsigned long long *sbase, const unsigned voff, const int nch, kr_v4u (&g)[KR_POLL_CHUNKS][1]) {
+        if (nch > 2)
+            asm volatile(KR_PLS(0, 4, 5, 0) KR_PLS(1, 4, 5, 1024) KR_PLS(2, 4, 5, 2048) KR_PLS(3, 4, 5, 3072) "s_waitcnt vmcnt(0)"
+                         : "=&v"(g[0][0]), "=&v"(g[1][0]), "=&v"(g[2][0]), "=&v"(g[3][0]) : "v"(voff), "s"(sbase) : "memory");
+        else if (nch > 1)
+            asm volatile(KR_PLS(0, 2, 3, 0) KR_PLS(1, 2, 3, 1024) "s_waitcnt vmcnt(0)" : "=&v"(g[0][0]), "=&v"(g[1][0]) : "v"(voff), "s"(sbase) : "memory");
+        else
+            asm volatile(KR_PLS(0, 1, 2, 0) "s_waitcnt vmcnt(0)" : "=&v"(g[0][0]) : "v"(voff), "s"(sbase) : "memory");
+    }
+};
+template <> struct KrPollLsb<4> {   // slot = two 16-byte words {d0, d1}, {d2, d3}; 64 slots = 2 KB
+    static constexpr int WORDS = 2;
+    static __device__ __forceinline__ void pass(const unsigned long long *sbase, const unsigned voff, const int nch, kr_v4u (&g)[KR_POLL_CHUNKS][2]) {
+        if (nch > 2) {
+            const unsigned voff2 = voff + 4096u;
+            asm volatile(KR_PLS(0, 8, 10, 0) KR_PLS(1, 8, 10, 16) KR_PLS(2, 8, 10, 2048) KR_PLS(3, 8, 10, 2064)
+                         KR_PLS(4, 9, 10, 0) KR_PLS(5, 9, 10, 16) KR_PLS(6, 9, 10, 2048) KR_PLS(7, 9, 10, 2064) "s_waitcnt vmcnt(0)"
+                         : "=&v"(g[0][0]), "=&v"(g[0][1]), "=&v"(g[1][0]), "=&v"(g[1][1]), "=&v"(g[2][0]), "=&v"(g[2][1]),
+                           "=&v"(g[3][0]), "=&v"(g[3][1])
+                         : "v"(voff), "v"(voff2), "s"(sbase) : "memory");
+        } else if (nch > 1)
+            asm volatile(KR_PLS(0, 4, 5, 0) KR_PLS(1, 4, 5, 16) KR_PLS(2, 4, 5, 2048) KR_PLS(3, 4, 5, 2064) "s_waitcnt vmcnt(0)"
+                         : "=&v"(g[0][0]), "=&v"(g[0][1]), "=&v"(g[1][0]), "=&v"(g[1][1]) : "v"(voff), "s"(sbase) : "memory");
+        else
+            asm volatile(KR_PLS(0, 2, 3, 0) KR_PLS(1, 2, 3, 16) "s_waitcnt vmcnt(0)" : "=&v"(g[0][0]), "=&v"(g[0][1]) : "v"(voff), "s"(sbase) : "memory");
+    }
+};
 template <int LMAX>
-__device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int par, const unsigned tag, const int lane, double (&tot)[LMAX]) {
+__device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par, const unsigned phase, const int lane, double (&tot)[LMAX]) {
+    static_assert(LMAX == 2 || LMAX == 4, "slot = LMAX doubles in 16-byte words");
+    constexpr int WORDS = KrPollLsb<LMAX>::WORDS;
     const int L = a.L, P = a.P;
-    const unsigned long long t0 = kr_realtime();
-    for (unsigned spins = 1;; ++spins) {
-        bool ok = true;
+    bool ok = true;
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
-        for (int q0 = 0; q0 < P; q0 += 64 * KR_POLL_CHUNKS) {
-            unsigned long long g[KR_POLL_CHUNKS][2 * LMAX];
+    for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
+    for (int q0 = 0; q0 < P; q0 += 64 * KR_POLL_CHUNKS) {
+        const int left = P - q0, nch = (left + 63) >> 6;   // wave-uniform
+        const unsigned long long *sbase = a.mail + ((size_t)par * P + q0) * KR_SLOT_GRANULES;
+        kr_v4u g[KR_POLL_CHUNKS][WORDS];
+        KrPollLsb<LMAX>::pass(sbase, (unsigned)lane * (8u * LMAX), nch, g);
 #pragma unroll
-            for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
-                if (q0 + 64 * c < P) {
-                    const int q = min(q0 + 64 * c + lane, P - 1);
-                    kr_gu64 *sq = (kr_gu64 *)(a.mail + ((size_t)par * P + q) * KR_SLOT_GRANULES);
+        for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
+            if (c < nch) {
+                const bool mine = (q0 + 64 * c + lane) < P;
 #pragma unroll
-                    for (int w = 0; w < 2 * LMAX; ++w) g[c][w] = __hip_atomic_load(sq + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
-                if (q0 + 64 * c < P) {
-                    const bool mine = (q0 + 64 * c + lane) < P;
-#pragma unroll
-                    for (int l = 0; l < LMAX; ++l) {
-                        if (l < L) {
-                            const unsigned long long g0 = g[c][2 * l], g1 = g[c][2 * l + 1];
-                            const bool good = ((unsigned)(g0 >> 32) == tag) & ((unsigned)(g1 >> 32) == tag);
-                            ok = ok & (good | !mine);
-                            const unsigned long long bits = (g1 << 32) | (g0 & 0xffffffffull);
-                            tot[l] += mine ? __longlong_as_double((long long)bits) : 0.0;
-                        }
+                for (int l = 0; l < LMAX; ++l) {
+                    if (l < L) {
+                        const unsigned lo = (l & 1) ? g[c][l >> 1].z : g[c][l >> 1].x, hi = (l & 1) ? g[c][l >> 1].w : g[c][l >> 1].y;
+                        ok = ok & (((lo & 1u) == phase) | !mine);
+                        tot[l] += mine ? __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)) : 0.0;
                     }
                 }
             }
         }
-        if (__all(ok)) break;
+    }
+    return ok;
+}
+// Slot value of a partial sum: its bits with the LSB forced to the phase.
+__device__ __forceinline__ unsigned long long kr_slot_bits(const double v, const unsigned phase) {
+    return ((unsigned long long)__double_as_longlong(v) & ~1ull) | (unsigned long long)phase;
+}
+
+// One wave gathers all P slots of buffer `par` until every slot carries `phase`; tot = sum over the slots, same order as in
+// kr_exchange.  Bounded; false = gave up (the caller's wave 0 flags it).
+template <int LMAX>
+__device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int par, const unsigned phase, const int lane, double (&tot)[LMAX]) {
+    const unsigned long long t0 = kr_realtime();
+    for (unsigned spins = 1;; ++spins) {
+        if (__all(kr_poll_pass<LMAX>(a, par, phase, lane, tot))) break;
         if ((spins & 63u) == 0u) {
             const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (st != 0u || kr_realtime() - t0 > KR_SPIN_TIMEOUT_TICKS) return false;
@@ -414,7 +456,10 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
     // the TAG, not from the step index, so that consecutive events alternate buffers across launches as well:
     // with peers on other GPUs nothing separates one launch's last step from the next launch's first one.
     const unsigned tag = a.epoch_base + (unsigned)n + 1u;
-    const int par = (int)(tag & 1u);
+    const int par = (int)(tag & 1u);                       // buffer of the mailbox between GPUs (xmail)
+    // mailbox inside the GPU: buffer and phase from the step index of THIS launch (the mailbox is zeroed in front of it)
+    const int lpar = n & 1;
+    const unsigned phase = (((unsigned)n >> 1) & 1u) ^ 1u;
 
     // 1. the ROWS row owners of the workgroup deposit their partial sums
     if (writer) {
@@ -435,14 +480,12 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             }
             tot1[l] = v;
         }
-        if (lane < 2 * L) {
+        if (lane < L) {
             double v = 0.0;
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) if (l == (lane >> 1)) v = tot1[l];
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-            const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-            const unsigned long long *dst = a.mail + ((size_t)par * P + wg) * KR_SLOT_GRANULES + lane;
-            const unsigned long long val = ((unsigned long long)tag << 32) | half;
+            for (int l = 0; l < LMAX; ++l) if (l == lane) v = tot1[l];
+            const unsigned long long *dst = a.mail + ((size_t)lpar * P + wg) * KR_SLOT_GRANULES + lane;
+            const unsigned long long val = kr_slot_bits(v, phase);
             asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
         }
     }
@@ -455,7 +498,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
         double tf[LMAX];
         const int W = a.world;
-        if (kr_gather_slots<LMAX>(a, par, tag, lane, tf) && lane < 2 * L * W) {
+        if (kr_gather_slots<LMAX>(a, lpar, phase, lane, tf) && lane < 2 * L * W) {
             const int r = lane / (2 * L), g = lane % (2 * L), l = g >> 1;
             double v = 0.0;
 #pragma unroll
@@ -482,17 +525,21 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         }
         if (!(P == 1 && a.world == 1)) {
             // 2. publish this workgroup's partial
-            kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)par * P + wg) * KR_SLOT_GRANULES);
-            if (SCHED == 0 && lane < 2 * L) {
+            kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)lpar * P + wg) * KR_SLOT_GRANULES);
+            if (SCHED == 0 && lane < L) {
                 double v = 0.0;
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l) if (l == (lane >> 1)) v = tot[l];
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-                __hip_atomic_store(slot + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                for (int l = 0; l < LMAX; ++l) if (l == lane) v = tot[l];
+                __hip_atomic_store(slot + lane, kr_slot_bits(v, phase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+#ifdef KR_ARRIVALS  // diagnostic build: when did every workgroup publish / complete two exchanges in the middle of the sweep
+            const bool arr = a.debug != nullptr && lane == 0 && (n == a.NT / 2 || n == a.NT / 2 + 1);
+            if (arr) a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2)] = kr_realtime();
+#endif
             work();
+#ifdef KR_ARRIVALS
+            if (arr) a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 1] = kr_realtime();
+#endif
             if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
             // 3. gather all P slots (lane handles slots lane, lane+64, ...), bounded spin.  With peers on other GPUs only
             //    the forwarding wave gathers them (one poller instead of P: the stores become visible sooner); everybody
@@ -500,39 +547,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             const unsigned long long t0 = kr_realtime();
             unsigned spins = 0;
             for (; a.world == 1;) {
-                bool ok = true;
-#pragma unroll
-                for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
-                for (int q0 = 0; q0 < P; q0 += 64 * KR_POLL_CHUNKS) {
-                    // issue every load of the pass back to back (no data-dependent branch in between), wait once
-                    unsigned long long g[KR_POLL_CHUNKS][2 * LMAX];
-#pragma unroll
-                    for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
-                        if (q0 + 64 * c < P) {  // wave-uniform
-                            const int q = min(q0 + 64 * c + lane, P - 1);
-                            kr_gu64 *sq = (kr_gu64 *)(a.mail + ((size_t)par * P + q) * KR_SLOT_GRANULES);
-#pragma unroll
-                            for (int w = 0; w < 2 * LMAX; ++w)
-                                g[c][w] = __hip_atomic_load(sq + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
-                        if (q0 + 64 * c < P) {
-                            const bool mine = (q0 + 64 * c + lane) < P;
-#pragma unroll
-                            for (int l = 0; l < LMAX; ++l) {
-                                if (l < L) {
-                                    const unsigned long long g0 = g[c][2 * l], g1 = g[c][2 * l + 1];
-                                    const bool good = ((unsigned)(g0 >> 32) == tag) & ((unsigned)(g1 >> 32) == tag);
-                                    ok = ok & (good | !mine);
-                                    const unsigned long long bits = (g1 << 32) | (g0 & 0xffffffffull);
-                                    tot[l] += mine ? __longlong_as_double((long long)bits) : 0.0;
-                                }
-                            }
-                        }
-                    }
-                }
+                const bool ok = kr_poll_pass<LMAX>(a, lpar, phase, lane, tot);
                 if (__all(ok)) break;
                 if ((++spins & 63u) == 0u) {
                     const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -552,6 +567,9 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(tot[l]);
             }
+#ifdef KR_ARRIVALS
+            if (arr) { a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 2] = kr_realtime(); a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 3] = spins; }
+#endif
 
             // 4. inter-GPU hop, receiving side (the sending side is wave 2 of workgroup 0, above): every workgroup polls
             //    its own GPU's xmail and sums the ranks.

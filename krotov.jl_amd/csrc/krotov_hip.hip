@@ -846,11 +846,11 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
     CHK(hipMemset(h->psiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->chiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->gint_d, 0, std::max(L, KR_LMAX_CAP) * sizeof(double)));
-    h->mail_words = (size_t)2 * h->P * 16;  // up to 128-B slots (KR_SLOT_GRANULES <= 16)
+    h->mail_words = (size_t)2 * h->P * 16 + 64 * 4;  // room for 128-B slots; tail: a poll pass reads whole 64-slot chunks (kr_poll_pass)
     CHK(alloc_mailbox(h, &h->mail_d, h->mail_words, h->P));
     CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
-    CHK(dalloc(&h->debug_d, 8));
-    CHK(hipMemset(h->debug_d, 0, 8 * sizeof(unsigned long long)));
+    CHK(dalloc(&h->debug_d, 8 + 8 * 1024));   // 8 phase stamps + per-workgroup arrival stamps of diagnostic builds (KR_ARRIVALS)
+    CHK(hipMemset(h->debug_d, 0, (8 + 8 * 1024) * sizeof(unsigned long long)));
     h->debug_on = env_int("KROTOV_HIP_STAMPS", 0) != 0;
     CHK(dalloc(&h->status_d, KR_STATUS_WORDS));
     CHK(hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
@@ -939,6 +939,16 @@ static int one_debug_stamps(kr_handle *h, unsigned long long *out) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->debug_d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return KR_OK;
+}
+
+// Diagnostic builds (-DKR_ARRIVALS): per workgroup {publish, end of window work, completion, poll passes} x 2 exchanges, realtime ticks.
+static int one_debug_arrivals(kr_handle *h, unsigned long long *out, int words) {
+    if (!h || !out || words < 0 || words > 8 * 1024) return KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->debug_d + 8, (size_t)words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return KR_OK;
 }
 
@@ -1284,6 +1294,9 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     // next launch: first tag = last tag + 3 (odd step: buffer parity keeps alternating); 32-bit wrap-around is
     // harmless because every slot is rewritten every second event and tags are only compared for equality
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
+    // the mailbox inside the GPU validates its slots with one bit per double whose phase starts at 1 in every launch
+    // (kr_exchange): start from zeros
+    HIPCHK(h, hipMemsetAsync(h->mail_d, 0, h->mail_words * sizeof(unsigned long long), h->stream));
     int rc = ev_mark(h, 2, false);
     if (rc) return rc;
     if (h->rowsplit) {
@@ -1808,6 +1821,7 @@ extern "C" int kr_enable_timing(kr_handle *h, int on) {
 extern "C" int kr_get_timings(kr_handle *h, double *t) { return one_get_timings(is_group(h) ? h->subs[0] : h, t); }
 extern "C" int kr_get_info(kr_handle *h, int32_t *info) { return one_get_info(is_group(h) ? h->subs[0] : h, info); }
 extern "C" int kr_debug_stamps(kr_handle *h, unsigned long long *o) { return one_debug_stamps(is_group(h) ? h->subs[0] : h, o); }
+extern "C" int kr_debug_arrivals(kr_handle *h, unsigned long long *o, int words) { return one_debug_arrivals(is_group(h) ? h->subs[0] : h, o, words); }
 extern "C" int kr_set_initial_states(kr_handle *h, const double *psi0) {
     if (is_group(h)) { if (!psi0) return fail(h, KR_ERR_INVALID, "kr_set_initial_states: null"); return group_run(h, [h, psi0](kr_handle *s, int i) { return one_set_initial_states(s, psi0 + soff(h, i)); }); }
     return one_set_initial_states(h, psi0);

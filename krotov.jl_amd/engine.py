@@ -218,6 +218,13 @@ class HipEngine:
         self._chk(self._lib.kr_debug_stamps(self._h, a))
         return [int(x) for x in a]
 
+    def debug_arrivals(self, workgroups):
+        """Diagnostic builds (-DKR_ARRIVALS): array [workgroups][2 exchanges][publish, window end, completion, passes]."""
+        import numpy as np
+        a = (C.c_uint64 * (8 * workgroups))()
+        self._chk(self._lib.kr_debug_arrivals(self._h, a, 8 * workgroups))
+        return np.array(a, dtype=np.uint64).reshape(workgroups, 2, 4)
+
     def info(self):
         a = (C.c_int32 * 16)()
         self._chk(self._lib.kr_get_info(self._h, a))

@@ -132,6 +132,44 @@ __device__ __forceinline__ bool gather16_asm(const u64 *mail, int cnt, unsigned 
     return false;
 }
 
+// variant 11: ONE-BIT tags.  A slot is written by one wave, in step order, and a reader that has completed step n - 2 has seen the
+// slot's value of step n - 2 (same buffer by parity), so at step n it can only see that value or the new one: one bit tells them
+// apart.  The bit is the mantissa LSB of each double (forced to the phase (n >> 1) & 1, inverted so that zeroed memory is invalid
+// in the first two steps): every 8-byte double validates itself, a slot is L doubles = 16 B instead of 32 B of {tag32 | half}
+// granules, a poll pass reads half the bytes.  Costs one ulp of the partial sums.
+__device__ __forceinline__ bool gather_lsb(const u64 *mail, int cnt, unsigned phase, double (&tot)[2], int lane) {
+    const u64 *p0 = mail + 2 * (size_t)min(lane, cnt - 1);
+    const u64 *p1 = mail + 2 * (size_t)min(64 + lane, cnt - 1);
+    const u64 *p2 = mail + 2 * (size_t)min(128 + lane, cnt - 1);
+    const u64 *p3 = mail + 2 * (size_t)min(192 + lane, cnt - 1);
+    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+        u4 g[4];
+        if (cnt > 128)
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n global_load_dwordx4 %1, %5, off sc1\n"
+                         "global_load_dwordx4 %2, %6, off sc1\n global_load_dwordx4 %3, %7, off sc1\n s_waitcnt vmcnt(0)"
+                         : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+        else if (cnt > 64)
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n global_load_dwordx4 %1, %3, off sc1\n s_waitcnt vmcnt(0)"
+                         : "=&v"(g[0]), "=&v"(g[1]) : "v"(p0), "v"(p1) : "memory");
+        else
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=&v"(g[0]) : "v"(p0) : "memory");
+        bool ok = true;
+        tot[0] = tot[1] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (64 * c < cnt) {
+                const bool mine = (64 * c + lane) < cnt;
+                const bool good = ((g[c].x & 1u) == phase) & ((g[c].z & 1u) == phase);
+                ok = ok & (good | !mine);
+                tot[0] += mine ? __longlong_as_double((long long)(((u64)g[c].y << 32) | g[c].x)) : 0.0;
+                tot[1] += mine ? __longlong_as_double((long long)(((u64)g[c].w << 32) | g[c].z)) : 0.0;
+            }
+        }
+        if (__all(ok)) { tot[0] = wave_sum(tot[0]); tot[1] = wave_sum(tot[1]); return true; }
+    }
+    return false;
+}
+
 template <int NCH, int DEPTH>
 __device__ __forceinline__ bool gather16(__amdgpu_buffer_rsrc_t r, int base, int first, int cnt, unsigned tag, double (&tot)[2], int lane) {
     u4 cur[NCH][2];
@@ -162,9 +200,11 @@ __device__ __forceinline__ void publish(u64 *slot, unsigned tag, double v0, doub
 }
 
 // variants 4 (16-B buffer loads), 5 (same, two passes in flight), 6 (four waves poll 64 slots each), 7 (16-B global loads)
-__global__ __launch_bounds__(256) void exch16(int variant, u64 *mail, double *out, u64 *cyc, int P, int iters, int work, unsigned *fail) {
+__global__ __launch_bounds__(256) void exch16(int variant, int split, u64 *mail, double *out, u64 *cyc, int P, int iters, int work, unsigned *fail) {
     __shared__ double sp[2][4][2];
     __shared__ int sfail;
+    __shared__ __attribute__((aligned(16))) u64 spoll[512];
+    unsigned misses = 0;
     const int wg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)mail, 0, 2 * 256 * 32, 0x00020000);
     double acc0 = 0, acc1 = 0;
@@ -178,6 +218,63 @@ __global__ __launch_bounds__(256) void exch16(int variant, u64 *mail, double *ou
         const double v0 = 1.0 + wg * 1e-3 + n * 1e-6, v1 = -0.5 * v0;
         double tot[2];
         bool ok = true;
+        if (variant == 12 || variant == 13) {
+            // the update sweep's structure: publish -> window work (`work` sleep units) -> poll.  13: the poll starts after the work
+            // (what kr_exchange did); 12: the first pass is issued BEFORE the work as LDS-DMA (global_load_lds_dwordx4: no result
+            // registers to keep live across the work) and checked after it; a register pass only if that one missed.
+            const unsigned phase = ((tag + 1u) >> 1) & 1u;
+            const u64 *buf = mail + (size_t)par * P * 2;
+            if (wave == 0 && lane == 0) {
+                const u64 b0 = ((u64)__double_as_longlong(v0) & ~1ull) | phase, b1 = ((u64)__double_as_longlong(v1) & ~1ull) | phase;
+                u4 q; q.x = (unsigned)b0; q.y = (unsigned)(b0 >> 32); q.z = (unsigned)b1; q.w = (unsigned)(b1 >> 32);
+                const u64 *dst = buf + (size_t)wg * 2;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(q) : "memory");
+            }
+            bool done = false;
+            if (wave == 0) {
+                const int pieces = (P * 16 + 1023) >> 10;
+                const int w1 = (variant == 12) ? work * split / 100 : 0;
+                for (int w = 0; w < w1; ++w) __builtin_amdgcn_s_sleep(1);
+                if (variant == 12) {
+                    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void *)spoll;
+                    const unsigned voff = lane * 16u;
+                    for (int c = 0; c < pieces; ++c) {
+                        unsigned keep;
+                        const u64 *sb = buf + 128 * c;
+                        const unsigned ld = lds + 1024u * c;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(voff), "s"(sb), "s"(ld) : "memory");
+                    }
+                }
+                for (int w = w1; w < work; ++w) __builtin_amdgcn_s_sleep(1);
+                if (variant == 12) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    bool okl = true;
+                    tot[0] = tot[1] = 0.0;
+                    for (int c = 0; c < pieces; ++c) {
+                        const int q = 64 * c + lane;
+                        const u4 g = *(const u4 *)&spoll[2 * q];
+                        const bool mine = q < P;
+                        okl = okl & ((((g.x & 1u) == phase) & ((g.z & 1u) == phase)) | !mine);
+                        tot[0] += mine ? __longlong_as_double((long long)(((u64)g.y << 32) | g.x)) : 0.0;
+                        tot[1] += mine ? __longlong_as_double((long long)(((u64)g.w << 32) | g.z)) : 0.0;
+                    }
+                    if (__all(okl)) { tot[0] = wave_sum(tot[0]); tot[1] = wave_sum(tot[1]); done = true; }
+                    else if (lane == 0) ++misses;
+                }
+                if (!done) ok = gather_lsb(buf, P, phase, tot, lane);
+            }
+        } else
+        if (variant == 11) {
+            const unsigned phase = ((tag + 1u) >> 1) & 1u;  // first use of either buffer expects 1: zeroed memory is invalid
+            if (wave == 0 && lane == 0) {
+                const u64 b0 = ((u64)__double_as_longlong(v0) & ~1ull) | phase, b1 = ((u64)__double_as_longlong(v1) & ~1ull) | phase;
+                u4 q; q.x = (unsigned)b0; q.y = (unsigned)(b0 >> 32); q.z = (unsigned)b1; q.w = (unsigned)(b1 >> 32);
+                const u64 *dst = mail + ((size_t)par * P + wg) * 2;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(q) : "memory");
+            }
+            if (wave == 0) ok = gather_lsb(mail + (size_t)par * P * 2, P, phase, tot, lane);
+        } else
         if (variant == 9) {  // slots spread over 8 blocks 9 KB apart
             if (wave == 0) publish<__HIP_MEMORY_SCOPE_AGENT>(mail + (size_t)par * 10240 + slot_off<1>(wg), tag, v0, v1, lane);
         } else if (variant == 10) {  // one replica of the mailbox per XCD group (blockIdx % 8), replicas 9 KB apart
@@ -198,6 +295,8 @@ __global__ __launch_bounds__(256) void exch16(int variant, u64 *mail, double *ou
             }
         } else
         if (wave == 0) publish<__HIP_MEMORY_SCOPE_AGENT>(mail + ((size_t)par * P + wg) * LQ, tag, v0, v1, lane);
+        if (variant == 11 || variant == 12 || variant == 13) {
+        } else
         if (variant == 9) {
             if (wave == 0) ok = gather16_asm<1>(mail + (size_t)par * 10240, P, tag, tot, lane);
         } else if (variant == 10) {
@@ -220,10 +319,11 @@ __global__ __launch_bounds__(256) void exch16(int variant, u64 *mail, double *ou
         if (variant != 6 && wave != 0) { tot[0] = tot[1] = 0; }
         if (!ok) { if (threadIdx.x == 0) atomicAdd(fail, 1u); break; }
         acc0 += tot[0]; acc1 += tot[1];
-        for (int w = 0; w < work; ++w) __builtin_amdgcn_s_sleep(1);
+        if (variant < 12) for (int w = 0; w < work; ++w) __builtin_amdgcn_s_sleep(1);
+        else for (int w = 0; w < 16; ++w) __builtin_amdgcn_s_sleep(1);  // the rest of the step
     }
     const u64 t1 = wall_clock64();
-    if (threadIdx.x == 0) { out[2 * wg] = acc0; out[2 * wg + 1] = acc1; cyc[wg] = t1 - t0; }
+    if (threadIdx.x == 0) { out[2 * wg] = acc0; out[2 * wg + 1] = acc1; cyc[wg] = t1 - t0; if (variant == 12) cyc[wg] |= (u64)misses << 40; }
 }
 
 __global__ __launch_bounds__(64) void exch(int variant, u64 *mail, u64 *mailB, double *out, u64 *cyc, unsigned *xcc,
@@ -272,17 +372,22 @@ __global__ __launch_bounds__(64) void exch(int variant, u64 *mail, u64 *mailB, d
 
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+    const int split = argc > 2 ? atoi(argv[2]) : 0;   // variant 12: the early pass is issued after split % of the window work
+    const int only = argc > 3 ? atoi(argv[3]) : -1;
     u64 *mail, *mailB, *cyc; double *out; unsigned *xcc, *fail;
-    hipMalloc(&mail, 2 * 10240 * 8);
+    // MAILMEM=1: uncached allocation (what the library uses with >= 64 pollers)
+    if (getenv("MAILMEM") && atoi(getenv("MAILMEM")) == 1) { if (hipExtMallocWithFlags((void **)&mail, 2 * 10240 * 8, hipDeviceMallocUncached) != hipSuccess) { printf("uncached alloc failed\n"); return 1; } }
+    else hipMalloc(&mail, 2 * 10240 * 8);
     hipMalloc(&mailB, 2 * 8 * LQ * 8);
     hipMalloc(&out, 256 * 2 * 8); hipMalloc(&cyc, 256 * 8); hipMalloc(&xcc, 256 * 4); hipMalloc(&fail, 4);
     for (int P : {8, 64, 256}) {
-        for (int work : {0, 64}) {
-            for (int variant = 0; variant < 11; ++variant) {
-                if (variant == 1 && P > 8) continue;  // sc0 loads hit the (stale) L1: never completes
+        for (int work : {0, 32, 64}) {
+            for (int variant = 0; variant < 14; ++variant) {
+                if (variant == 1 && P > 8) continue;
+                if (only >= 0 && variant < only) continue;  // sc0 loads hit the (stale) L1: never completes
                 hipMemset(mail, 0, 2 * 10240 * 8); hipMemset(mailB, 0, 2 * 8 * LQ * 8);
                 hipMemset(fail, 0, 4);
-                if (variant >= 4) hipLaunchKernelGGL(exch16, dim3(P), dim3(variant == 6 ? 256 : 64), 0, 0, variant, mail, out, cyc, P, iters, work, fail);
+                if (variant >= 4) hipLaunchKernelGGL(exch16, dim3(P), dim3(variant == 6 ? 256 : 64), 0, 0, variant, split, mail, out, cyc, P, iters, work, fail);
                 else hipLaunchKernelGGL(exch, dim3(P), dim3(64), 0, 0, variant, mail, mailB, out, cyc, xcc, P, iters, work, fail);
                 if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
                 std::vector<u64> c(P); std::vector<double> o(2 * P); std::vector<unsigned> x(P); unsigned f;
@@ -292,6 +397,8 @@ int main(int argc, char **argv) {
                 for (int w = 1; w < P; ++w) same = same && o[2 * w] == o[0] && o[2 * w + 1] == o[1];
                 for (int w = 8; w < P; ++w) rr = rr && ((x[w] & 15) == (x[w - 8] & 15));
                 // wall_clock64: 100 MHz
+                const unsigned long long miss0 = c[0] >> 40; c[0] &= (1ull << 40) - 1;
+                if (variant == 12) printf("   (variant 12: early pass missed in %llu of %d steps at workgroup 0)\n", miss0, iters + 8);
                 printf("P=%3d work=%2d variant=%d: %.3f us/exchange  (sum %.6f, all equal %d, fails %u, wg%%8 shares XCC %d, xcc[0..7]=%u %u %u %u %u %u %u %u)\n",
                        P, work, variant, (double)c[0] / iters * 0.01, o[0], (int)same, f, (int)rr,
                        x[0] & 15, x[1 % P] & 15, x[2 % P] & 15, x[3 % P] & 15, x[4 % P] & 15, x[5 % P] & 15, x[6 % P] & 15, x[7 % P] & 15);
