@@ -168,8 +168,9 @@ int kr_read_storage(kr_handle *h, int which, int k, int n, double *out /* [N] */
 /* Introspection for bench / tests.  info_out (16 ints): {NP, n_workgroups, traj_per_wg, threads,
  * KT, LMAX variant, K padded, store_fw, JQ, precomputed propagators, row-split R, exchange poll delay
  * (units of 128 cycles, -1 = classic schedule; measured once by kr_create),
- * Hermitian-controls kernel variant in use, matrix-core update sweep, generic (multi-pass) known sweeps, generic / stepped
- * update sweep, exchange in use (kr_exchange), 0}.
+ * Hermitian-controls kernel variant in use, matrix-core update sweep, generic (multi-pass) known sweeps,
+ * [15] = generic / stepped update sweep (bit 0) | exchange in use (kr_exchange, bits 4-5) | economized step polynomial in the
+ * update sweep (bit 8: all generators Hermitian)}.
  * kr_enable_timing(h, 1) starts a window in which every sweep-kernel launch is bracketed by HIP
  * events on the handle's stream; kr_get_timings syncs the stream and returns, per kind
  * {forward, backward, update}: {sum of kernel durations in ms, number of launches} (6 doubles). */

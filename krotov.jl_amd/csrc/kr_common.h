@@ -7,6 +7,7 @@
 #define KR_LMAX_CAP 4           // largest L of the register-resident kernels
 #define KR_THETA_MAX 1.0        // largest ||H dt|| handled by one Taylor sub-step
 #define KR_MAX_ORDER 48
+#define KR_ECON_W 32           // doubles per row of the economized-polynomial table: [0] a0, [1] a1, [j] a_j / a_{j-1} (2 <= j <= m <= 29), [30] theta_c, [31] m
 #ifndef KR_APPLY_JQ64
 #define KR_APPLY_JQ64 8          // lanes per row of the apply sweep at NP = 64 (8: 512-thread workgroups)
 #endif
@@ -41,6 +42,9 @@ struct KrSweepArgs {
     int xpoll_delay;           // world > 1: extra wait (x 128 cycles) before a workgroup starts polling xmail
     int gather_delay_local;    // the same when the all-gather stays inside one XCD's L2
     int gather_delay;          // row-split all-gather: the polling wave starts after gather_delay x 128 cycles
+    // Economized step polynomial of the update sweep (Hermitian generators; kr_device.h: KrEcon): rows [G][NT][KR_ECON_W] written by
+    // kr_econ_rows_kernel (krotov_hip.hip) from the guess pulses in front of every update sweep; nullptr = Taylor everywhere.
+    const double *econ;
     int poll_delay;            // exchange schedule 1 (kr_exchange): wave 0 starts polling after poll_delay x 128 cycles
     unsigned long long *mail;  // [2][P][2*LMAX] granules {tag32 | half of a double}
     unsigned long long *xmail; // [2][world][2*LMAX] inter-GPU granules (local memory, peers write)

@@ -120,6 +120,26 @@ __device__ __forceinline__ double kr_rinv_lane(const double mine, const int j) {
     return __hiloint2double(hi, lo);
 }
 
+// Economized step polynomial (round 2).  For a Hermitian generator the step exp(-i H fs) psi needs a polynomial that is accurate
+// on the segment z = -i fs [-||H||, ||H||] only; truncating the Chebyshev expansion of exp(-i theta_c x) at degree m and rewriting
+// it in powers of z gives real coefficients a_j(theta_c), and the Horner loop of the kernels evaluates it unchanged with the ratios
+// g_j = a_j / a_{j-1} in place of Taylor's 1 / j:   psi' = a_0 psi + a_1 y_1,  y_m = v,  y_{j-1} = v + g_j z y_j,  v = z psi.
+// Same truncation bound (2 sum_{k>m} |J_k(theta_c)| <= tol), one to three degrees -- i.e. matvec rounds -- fewer than Taylor
+// (theta = 0.12: 9 against 10; 0.5: 12 against 14; C3's 0.067: 7 against 8).  theta_c = 1.01 x the bound of ||H(eps_guess) dt||
+// of the step, known before the sweep; a step whose updated pulse leaves that margin takes the Taylor plan (always valid).
+// Lane j (mod 32) of every wave holds entry j of the step's row (KR_ECON_W), fetched one step ahead.
+struct KrEcon { bool on; double a0, a1; };
+__device__ __forceinline__ KrEcon kr_econ_select(const double ec, const double theta, int &s, int &m) {
+    KrEcon r;
+    r.on = false; r.a0 = 1.0; r.a1 = 1.0;
+    const int me = (int)kr_rinv_lane(ec, 31);
+    if (me > 0 && theta <= kr_rinv_lane(ec, 30)) {
+        r.on = true; m = me; s = 1;
+        r.a0 = kr_rinv_lane(ec, 0); r.a1 = kr_rinv_lane(ec, 1);
+    }
+    return r;
+}
+
 __device__ __forceinline__ unsigned long long kr_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 
 typedef __attribute__((address_space(1))) unsigned long long kr_gu64;
@@ -749,13 +769,17 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         eg_nx[l] = (l < L) ? a.eps[(size_t)l * NT] : 0.0;
         al_nx[l] = (l < L) ? a.alpha[(size_t)l * NT] : 0.0;
     }
+    const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
+    double ec_nx = econ_rows ? econ_rows[0] : 0.0;
     for (int n = 0; n < NT; ++n) {
         const double dt = dt_nx;
+        const double ec = ec_nx;
         double eg[LMAX], al[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) { eg[l] = eg_nx[l]; al[l] = al_nx[l]; }
         if (n + 1 < NT) {
             dt_nx = a.dt[n + 1];
+            if (econ_rows) ec_nx = econ_rows[(size_t)(n + 1) * KR_ECON_W];
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) {
                 if (l < L) { eg_nx[l] = a.eps[(size_t)l * NT + n + 1]; al_nx[l] = a.alpha[(size_t)l * NT + n + 1]; }
@@ -855,6 +879,8 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         theta *= fabs(dt);
         int s, m;
         kr_plan_fast(a, my_thr, theta, s, m);
+        const KrEcon eco = kr_econ_select(ec, theta, s, m);
+        const double my_g = eco.on ? ec : my_rinv;   // Horner ratios of this step, lane j holds g_j
 
         // H(eps_new) = H(eps_guess) + sum_l (eps_new - eps_guess)_l H_l   (H(eps_guess) was formed before phase A)
 #pragma unroll
@@ -896,7 +922,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
             for (int q = 0; q < KT; ++q) { yr[q] = vr[q]; yi[q] = vi[q]; }
             for (int j = m; j >= 2; --j) {
-                const double f = fs * kr_rinv_lane(my_rinv, j);
+                const double f = fs * kr_rinv_lane(my_g, j);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     const int tq = q * SG + team;
@@ -912,8 +938,8 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
             if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB2 += t - t_prev; }
 #pragma unroll
             for (int q = 0; q < KT; ++q) {
-                pr[q] += yr[q];
-                pim[q] += yi[q];
+                pr[q] = fma(eco.a1, yr[q], eco.a0 * pr[q]);     // (Taylor: a0 = a1 = 1, the plain sum)
+                pim[q] = fma(eco.a1, yi[q], eco.a0 * pim[q]);
                 if (writer) sx[cur ^ 1][q * SG + team][pi_] = make_double2(pr[q], pim[q]);
             }
             if (s == 1 && memwave && n + 1 + HERM < NT) {  // hand chi(t_{n+1}) (HERM: chi(t_{n+2})) to the next step

@@ -236,13 +236,17 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         eg_nx[l] = (l < L) ? a.eps[(size_t)l * NT] : 0.0;
         al_nx[l] = (l < L) ? a.alpha[(size_t)l * NT] : 0.0;
     }
+    const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
+    double ec_nx = econ_rows ? econ_rows[0] : 0.0;
     for (int n = 0; n < NT; ++n) {
         const double dtn = dt_nx;
+        const double ec = ec_nx;
         double eg[LMAX], al[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) { eg[l] = eg_nx[l]; al[l] = al_nx[l]; }
         if (n + 1 < NT) {
             dt_nx = a.dt[n + 1];
+            if (econ_rows) ec_nx = econ_rows[(size_t)(n + 1) * KR_ECON_W];
 #pragma unroll
             for (int l = 0; l < LMAX; ++l)
                 if (l < L) { eg_nx[l] = a.eps[(size_t)l * NT + n + 1]; al_nx[l] = a.alpha[(size_t)l * NT + n + 1]; }
@@ -321,6 +325,8 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         theta *= fabs(dtn);
         int s, m;
         kr_plan_fast(a, my_thr, theta, s, m);
+        const KrEcon eco = kr_econ_select(ec, theta, s, m);   // economized step polynomial (kr_device.h) where the step's row allows it
+        const double my_g = eco.on ? ec : my_rinv;
         const double fs = (s == 1) ? dtn : dtn / (double)s;
 
         // ---- psi <- exp(-i H(eps_new) dt) psi.  -i H(eps_new) psi = D_0 + sum e_l D_l is known already, so the first
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB1 += t - t_prev; }
         int wb = 1;
         for (int j = m; j >= 2; --j) {
-            const double f = fs * kr_rinv_lane(my_rinv, j);
+            const double f = fs * kr_rinv_lane(my_g, j);
             double d[TILES];
             kr_mf_apply<TILES, true>(Er, Ei, &sy[wb ^ 1][0][0], boff, kb0, d);   // (own rows first: 1016 -> 969 cycles per round at one tile, a wash at two)
 #pragma unroll
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB2 += t - t_prev; }
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            psi[t] += y[t];
+            psi[t] = fma(eco.a1, y[t], eco.a0 * psi[t]);   // (Taylor: a0 = a1 = 1)
             kr_mf_put(sx[cur ^ 1][t], doff, zoff, zs, psi[t]);
         }
         // chi(t_{n+1}) (HERM: chi(t_{n+2})) from the prefetch registers into LDS (a macro, not a lambda: captured by

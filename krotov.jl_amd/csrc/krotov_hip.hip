@@ -77,6 +77,8 @@ struct kr_handle {
     unsigned long long *mail_d = nullptr, *xmail_d = nullptr;
     size_t mail_words = 0;
     bool herm = false;    // every control operator Hermitian: update kernel variant HERM (kr_device.h)
+    bool econ = false;    // every generator Hermitian (drift and control operators): economized step polynomial in the update sweep
+    double *econ_d = nullptr;   // [G][NT][KR_ECON_W] rows, rewritten from the guess pulses in front of every update sweep
     int poll_delay = -1;  // exchange schedule of the update sweep (KrSweepArgs::poll_delay), set by calibrate_exchange
     unsigned long long *peer_xmail[8]{};
     bool peers_connected = false;
@@ -216,6 +218,60 @@ static int env_int(const char *name, int dflt) {
 
 // ---- small device kernels for the standard functionals ---------------------
 // tau_k = <tgt_k|psi_k(T)>  (taus!, optimize.jl:381); one wave per trajectory.
+// Rows of the economized step polynomial (kr_device.h: KrEcon), one thread per (generator, interval): theta_c = margin x the
+// bound of ||H(eps_guess_n) dt_n||; Chebyshev coefficients (2 - delta_k0) J_k(theta_c) by the ascending series (theta_c <= 1),
+// smallest degree m whose dropped tail is below tol, then the same polynomial in powers of z = -i H dt:
+//   a_j = theta_c^-j  sum_p (-1)^p (2 - delta) J_{j+2p}(theta_c) t_{j+2p, j},   T_k(x) = sum_j t_kj x^j.
+// Row: [0] a_0, [1] a_1, [j] a_j / a_{j-1}, [30] theta_c, [31] m; m = 0: no row (the step takes the Taylor plan).
+#define KR_ECON_KMAX 40
+__global__ void kr_econ_rows_kernel(const double *eps, const double *dt, const double *nrm, int G, int NT, int L, double tol, double margin,
+                                    double *rows) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= G * NT) return;
+    const int g = idx / NT, n = idx % NT;
+    double *row = rows + (size_t)idx * KR_ECON_W;
+    for (int j = 0; j < KR_ECON_W; ++j) row[j] = 0.0;
+    double th = nrm[(size_t)g * (1 + KR_LMAX_CAP)];
+    for (int l = 0; l < L && l < KR_LMAX_CAP; ++l) th += fabs(eps[(size_t)l * NT + n]) * nrm[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l];
+    th *= fabs(dt[n]) * margin;
+    if (!(th > 0.0) || th > KR_THETA_MAX) return;
+    double c[KR_ECON_KMAX + 1];
+    const double half = 0.5 * th, q = -half * half;
+    double pref = 1.0;
+    for (int k = 0; k <= KR_ECON_KMAX; ++k) {
+        if (k > 0) pref *= half / (double)k;
+        double sum = 1.0, term = 1.0;
+        for (int i = 1; i <= 24; ++i) { term *= q / ((double)i * (double)(k + i)); sum += term; }
+        c[k] = (k ? 2.0 : 1.0) * pref * sum;
+    }
+    int m = 0;
+    double tail = 0.0;
+    for (int k = KR_ECON_KMAX; k >= 2; --k) {   // smallest m >= 1 with sum_{k > m} |c_k| <= tol
+        tail += fabs(c[k]);
+        if (tail > tol) { m = k; break; }
+    }
+    if (m == 0) m = 1;
+    if (m > 29) return;
+    double acc[30], tp[30], tc[30];   // a_j (before the theta^-j), T_{k-1}, T_k
+    for (int j = 0; j < 30; ++j) { acc[j] = 0.0; tp[j] = 0.0; tc[j] = 0.0; }
+    tc[0] = 1.0;   // T_0
+    for (int k = 0; k <= m; ++k) {
+        for (int j = k & 1; j <= k; j += 2) acc[j] += ((((k - j) >> 1) & 1) ? -1.0 : 1.0) * c[k] * tc[j];
+        // T_{k+1} = 2 x T_k - T_{k-1}
+        double tn[30];
+        for (int j = 0; j < 30; ++j) tn[j] = ((j > 0) ? 2.0 * tc[j - 1] : 0.0) - tp[j];
+        if (k == 0) { for (int j = 0; j < 30; ++j) tn[j] = 0.0; tn[1] = 1.0; }   // T_1 = x
+        for (int j = 0; j < 30; ++j) { tp[j] = tc[j]; tc[j] = tn[j]; }
+    }
+    double ti = 1.0;
+    for (int j = 0; j <= m; ++j) { acc[j] *= ti; ti /= th; }
+    row[0] = acc[0];
+    row[1] = acc[1];
+    for (int j = 2; j <= m; ++j) row[j] = acc[j] / acc[j - 1];
+    row[30] = th;
+    row[31] = (double)m;
+}
+
 __global__ void kr_tau_kernel(const double2 *tgt, const double2 *psi, double2 *tau, int N, int K) {
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= K) return;
@@ -558,7 +614,7 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
-                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d,
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d,
                     h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected && !h->peers_in_process)
@@ -714,6 +770,22 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
                 for (int r = 0; r <= c; ++r)
                     if (M[(size_t)c * N + r] != std::conj(M[(size_t)r * N + c])) { h->herm = false; break; }
         }
+    }
+    // Economized step polynomial (KrEcon, kr_device.h): needs a real spectrum, i.e. EVERY operator of every generator exactly
+    // Hermitian; register-resident update kernels only (N <= 64).  KROTOV_HIP_ECON = 0 switches it off.
+    h->econ = env_int("KROTOV_HIP_ECON", 1) != 0 && h->fast_ok && !h->gen_update && !h->rowsplit && h->NP <= 64;
+    for (int g = 0; g < G && h->econ; ++g) {
+        for (int m = 0; m <= L && h->econ; ++m) {
+            if (m > 0 && !((present[g] >> (m - 1)) & 1u)) continue;
+            const zc *M = (m == 0) ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn;
+            for (int c = 0; c < N && h->econ; ++c)
+                for (int r = 0; r <= c; ++r)
+                    if (M[(size_t)c * N + r] != std::conj(M[(size_t)r * N + c])) { h->econ = false; break; }
+        }
+    }
+    if (h->econ) {
+        CHK(dalloc(&h->econ_d, (size_t)G * NT * KR_ECON_W));
+        CHK(hipMemset(h->econ_d, 0, (size_t)G * NT * KR_ECON_W * sizeof(double)));
     }
     for (int adj = 0; adj < 2 && h->fast_ok; ++adj) {
         for (int g = 0; g < G; ++g)
@@ -927,7 +999,7 @@ static int one_get_info(kr_handle *h, int32_t *info) {
     if (!h || !info) return KR_ERR_INVALID;
     memset(info, 0, 16 * sizeof(int32_t));
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
-    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay; info[12] = (h->herm && h->NP <= 64) ? 1 : 0; info[13] = h->mfma_sweep ? 1 : 0; info[14] = h->gen_known ? 1 : 0; info[15] = (h->gen_update ? 1 : 0) | (h->exchange << 4);
+    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay; info[12] = (h->herm && h->NP <= 64) ? 1 : 0; info[13] = h->mfma_sweep ? 1 : 0; info[14] = h->gen_known ? 1 : 0; info[15] = (h->gen_update ? 1 : 0) | (h->exchange << 4) | (h->econ ? 256 : 0);
     if (h->mfma_sweep) info[3] = 256;
     // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
     return KR_OK;
@@ -1004,6 +1076,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.gen_div = 1;
     a.wg_gen = (h->G > 1) ? h->wg_gen_d : nullptr;
     a.nrm_dev = h->nrm_d;
+    a.econ = nullptr;
     a.present_dev = h->present_d;
     a.status = h->status_d;
     a.debug = h->debug_on ? h->debug_d : nullptr;
@@ -1294,6 +1367,13 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     // next launch: first tag = last tag + 3 (odd step: buffer parity keeps alternating); 32-bit wrap-around is
     // harmless because every slot is rewritten every second event and tags are only compared for equality
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
+    if (h->econ) {   // rows of the economized step polynomial from this sweep's guess pulses (device-resident pulses included)
+        const int rows = h->G * h->cfg.NT;
+        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, h->stream, eps_guess_dev, h->dt_d, h->nrm_d, h->G, h->cfg.NT, h->cfg.L,
+                           h->tol, 1.01, h->econ_d);
+        HIPCHK(h, hipGetLastError());
+        a.econ = h->econ_d;
+    }
     // the mailbox inside the GPU validates its slots with one bit per double whose phase starts at 1 in every launch
     // (kr_exchange): start from zeros
     HIPCHK(h, hipMemsetAsync(h->mail_d, 0, h->mail_words * sizeof(unsigned long long), h->stream));

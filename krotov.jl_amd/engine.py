@@ -233,6 +233,7 @@ class HipEngine:
         ge = d.pop("generic_update_exchange")
         d["generic_update"] = ge & 1
         d["exchange"] = ("auto", "mailbox", "rccl", "callback")[(ge >> 4) & 3]
+        d["economized_polynomial"] = (ge >> 8) & 1
         return d
 
     # per-step exchange outside the kernels (KR_EXCHANGE_RCCL / KR_EXCHANGE_CALLBACK)

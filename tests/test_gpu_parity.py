@@ -609,3 +609,51 @@ def test_matrix_core_sweep_variants(oracle_c, monkeypatch, herm):
         for k in range(K):
             psi[k] = o.step_propagator(H0[tg[k]], Hc[tg[k]], eps_o[:, n], base["tlist"][n + 1] - base["tlist"][n]) @ psi[k]
     assert _rel(eps_new, eps_o) < TOL_PULSE and np.max(np.abs(psiT1 - psi)) < 1e-10
+
+
+def _iterate(p, **kw):
+    K = p["psi0"].shape[0]
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, **kw) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
+        return eng.iteration(p["eps"], chiT, p["S"], p["lam"]), eng.info()
+
+
+def test_economized_step_polynomial(oracle_c, monkeypatch):
+    """Hermitian generators: the update sweep evaluates the Chebyshev-economized polynomial of the step (same truncation bound,
+    fewer matvec rounds) through the Taylor kernels' Horner loop.  It must agree with the Taylor plan (KROTOV_HIP_ECON=0) far inside
+    the parity tolerances, with the oracle at them, fall back to Taylor where the updated pulse leaves the 1 % margin the row of
+    the step was built for (large updates), and stay off for generators with a non-Hermitian drift."""
+    cases = [wl.dense_problem(64, 12, 256, 2, 171, 0.05, 5.0),     # C3's shape: VALU kernel, Hermitian-controls variant
+             wl.dense_problem(64, 8, 512, 2, 172, 0.05, 5.0),      # matrix-core sweep, one tile
+             wl.dense_problem(64, 6, 1024, 2, 173, 0.05, 5.0),     # matrix-core sweep, two tiles
+             wl.dense_problem(16, 20, 32, 1, 174, 0.1, 1.0),       # C2's shape
+             wl.dense_problem(33, 9, 5, 3, 175, 0.4, 2.0),         # larger ||H dt||: several degrees saved
+             wl.dense_problem(20, 10, 7, 2, 176, 0.1, 2e-3)]       # huge updates: most steps leave the margin -> Taylor plan
+    for ci, p in enumerate(cases):
+        res = {}
+        for mode in ["0", "1"]:
+            monkeypatch.setenv("KROTOV_HIP_ECON", mode)
+            res[mode], info = _iterate(p)
+            assert info["economized_polynomial"] == int(mode)
+        assert _rel(res["1"][0], res["0"][0]) < 1e-12, ci
+        assert np.max(np.abs(res["1"][2] - res["0"][2])) < 2e-13 * max(1.0, np.max(np.abs(res["0"][2]))), ci
+        monkeypatch.setenv("KROTOV_HIP_ECON", "1")
+        _run_case(oracle_c, p, check_storage=False)
+    # a looser tolerance: lower degrees on both plans, still consistent with each other at that tolerance
+    p = cases[4]
+    monkeypatch.setenv("KROTOV_HIP_ECON", "0")
+    tight, _ = _iterate(p)
+    out = {}
+    for mode in ["0", "1"]:
+        monkeypatch.setenv("KROTOV_HIP_ECON", mode)
+        out[mode], _ = _iterate(p, prop_tol=1e-9)
+    assert _rel(out["1"][0], out["0"][0]) < 1e-6 and _rel(out["1"][0], tight[0]) < 1e-6
+    # non-Hermitian drift: the polynomial is not valid off the real axis -> Taylor
+    monkeypatch.setenv("KROTOV_HIP_ECON", "1")
+    p = wl.dense_problem(12, 6, 5, 2, 177, 0.1, 2.0)
+    p["H0"] = p["H0"] - 0.05j * np.eye(12)
+    (_, _, _), info = _iterate(p)
+    assert info["economized_polynomial"] == 0
+    _run_case(oracle_c, p)
