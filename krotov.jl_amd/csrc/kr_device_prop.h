@@ -53,6 +53,9 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
     theta *= fabs(sdt);
     int s, m;
     kr_plan_fast(a, my_thr, theta, s, m);
+    // economized polynomial of the step (KrEcon, kr_device.h) where the sweep has rows for it: Hermitian generators, ||H dt|| <= 1
+    const KrEcon eco = kr_econ_select(a.econ ? a.econ[((size_t)gx.gen * NT + n) * KR_ECON_W + (lane & (KR_ECON_W - 1))] : 0.0, theta, s, m);
+    const double my_g = eco.on ? a.econ[((size_t)gx.gen * NT + n) * KR_ECON_W + (lane & (KR_ECON_W - 1))] : my_rinv;
     const double fs = (s == 1) ? sdt : sdt / (double)s;
 
     // H(eps_n) slice of this thread
@@ -89,14 +92,15 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
         int w = 1;  // sy[0] holds the current state
         for (int sub = 0; sub < s; ++sub) {
             for (int j = m; j >= 1; --j) {
-                const double f = fs * kr_rinv_lane(my_rinv, j);
+                const double f = fs * kr_rinv_lane(my_g, j);     // (economized: g_j, and a_1 at j = 1)
+                const double idc = (j == 1) ? eco.a0 : 1.0;     // coefficient of the vector itself: a_0 in the last round
 #pragma unroll
                 for (int b = 0; b < CB; ++b) {
                     const int tq = team * CB + b;
                     double sr, si;
                     kr_row_dot<JS, JQ>(Er, Ei, &sy[w ^ 1][tq][xoff], sr, si);
-                    const double yr = fma(f, si, pr[b]);
-                    const double yi = fma(-f, sr, pim[b]);
+                    const double yr = fma(f, si, idc * pr[b]);
+                    const double yi = fma(-f, sr, idc * pim[b]);
                     if (j == 1) { pr[b] = yr; pim[b] = yi; }
                     if (writer) sy[w][tq][pi_] = make_double2(yr, yi);
                 }
@@ -252,6 +256,10 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
     while (theta > KR_THETA_MAX && q < 30) { theta *= 0.5; ++q; }
     int s_unused, m;
     kr_plan_fast(a, my_thr, theta, s_unused, m);   // theta <= 1 here: table path
+    // economized polynomial of the step (KrEcon, kr_device.h): rows exist for Hermitian generators with ||H dt|| <= 1 (q = 0)
+    const double ec = (a.econ && q == 0) ? a.econ[((size_t)gx.gen * NT + n) * KR_ECON_W + (lane & (KR_ECON_W - 1))] : 0.0;
+    const KrEcon eco = kr_econ_select(ec, theta, s_unused, m);
+    const double my_g = eco.on ? ec : my_rinv;
     const double fs = ldexp(sdt, -q);
 
     // A fragments: A = -i fs H  ->  Ar = fs Hi,  Ai = -fs Hr  (row 16w + li, column 4t + lk)
@@ -275,20 +283,25 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
         Ai[t] = -fs * hr;
         nAi[t] = fs * hr;
     }
-    // Y = I
-    for (int idx = tid; idx < NP * NP; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        KR_YR(0)[r * KR_YS + c] = (r == c) ? 1.0 : 0.0;
-        KR_YI(0)[r * KR_YS + c] = 0.0;
+    // Horner round j = m needs no product: Y_{m-1} = c I + f_m A, written from the A fragments (c = a_0 when it is also the last)
+    {
+        const double fm = kr_rinv_lane(my_g, m), idm = (m == 1) ? eco.a0 : 1.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int col = 4 * t + lk;
+            KR_YR(0)[row * KR_YS + col] = fma(fm, Ar[t], (row == col) ? idm : 0.0);
+            KR_YI(0)[row * KR_YS + col] = fm * Ai[t];
+        }
     }
     __syncthreads();
 
     int cur = 0;
-    const int rounds = m + q;
+    const int rounds = (m - 1) + q;
     for (int rd = 0; rd < rounds; ++rd) {
-        const bool horner = (rd < m);
-        const int j = m - rd;  // Horner index m..1
-        const double f = horner ? kr_rinv_lane(my_rinv, j) : 1.0;
+        const bool horner = (rd < m - 1);
+        const int j = m - 1 - rd;  // Horner index m-1..1
+        const double f = horner ? kr_rinv_lane(my_g, j) : 1.0;
+        const double idc = (horner && j == 1) ? eco.a0 : 1.0;
         if (!horner) {  // squaring: the A fragments become this wave's row tile of Y
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int orow = 16 * w + lk + 4 * r, ocol = 16 * ct + li;
                 double vr = cr[r] * f, vi = ci[r] * f;
-                if (horner && orow == ocol) vr += 1.0;
+                if (horner && orow == ocol) vr += idc;
                 KR_YR(cur ^ 1)[orow * KR_YS + ocol] = vr;
                 KR_YI(cur ^ 1)[orow * KR_YS + ocol] = vi;
             }

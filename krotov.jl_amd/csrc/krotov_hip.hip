@@ -218,58 +218,64 @@ static int env_int(const char *name, int dflt) {
 
 // ---- small device kernels for the standard functionals ---------------------
 // tau_k = <tgt_k|psi_k(T)>  (taus!, optimize.jl:381); one wave per trajectory.
-// Rows of the economized step polynomial (kr_device.h: KrEcon), one thread per (generator, interval): theta_c = margin x the
+// Rows of the economized step polynomial (kr_device.h: KrEcon), one wave per (generator, interval): theta_c = margin x the
 // bound of ||H(eps_guess_n) dt_n||; Chebyshev coefficients (2 - delta_k0) J_k(theta_c) by the ascending series (theta_c <= 1),
 // smallest degree m whose dropped tail is below tol, then the same polynomial in powers of z = -i H dt:
 //   a_j = theta_c^-j  sum_p (-1)^p (2 - delta) J_{j+2p}(theta_c) t_{j+2p, j},   T_k(x) = sum_j t_kj x^j.
 // Row: [0] a_0, [1] a_1, [j] a_j / a_{j-1}, [30] theta_c, [31] m; m = 0: no row (the step takes the Taylor plan).
-#define KR_ECON_KMAX 40
-__global__ void kr_econ_rows_kernel(const double *eps, const double *dt, const double *nrm, int G, int NT, int L, double tol, double margin,
-                                    double *rows) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per row: lane k evaluates J_k, lane j the coefficient a_j (T_k's coefficients by the three-term recurrence, lane j holding
+// t_kj and taking t_k,j-1 from its neighbour), ~10 us for the N_T rows of a sweep.
+#define KR_ECON_KMAX 31
+__global__ __launch_bounds__(64) void kr_econ_rows_kernel(const double *eps, const double *dt, const double *nrm, int G, int NT, int L, double tol,
+                                                           double margin, double *rows) {
+    __shared__ double c[64];
+    const int idx = blockIdx.x, lane = threadIdx.x;
     if (idx >= G * NT) return;
     const int g = idx / NT, n = idx % NT;
     double *row = rows + (size_t)idx * KR_ECON_W;
-    for (int j = 0; j < KR_ECON_W; ++j) row[j] = 0.0;
     double th = nrm[(size_t)g * (1 + KR_LMAX_CAP)];
     for (int l = 0; l < L && l < KR_LMAX_CAP; ++l) th += fabs(eps[(size_t)l * NT + n]) * nrm[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l];
     th *= fabs(dt[n]) * margin;
-    if (!(th > 0.0) || th > KR_THETA_MAX) return;
-    double c[KR_ECON_KMAX + 1];
-    const double half = 0.5 * th, q = -half * half;
-    double pref = 1.0;
-    for (int k = 0; k <= KR_ECON_KMAX; ++k) {
-        if (k > 0) pref *= half / (double)k;
+    if (!(th > 0.0) || th > KR_THETA_MAX) {   // no row: the step takes the Taylor plan
+        if (lane < KR_ECON_W) row[lane] = 0.0;
+        return;
+    }
+    {   // c_k = (2 - delta_k0) J_k(th): (th/2)^k / k!  x  sum_i (-th^2/4)^i / (i! (k+1)...(k+i))
+        const double half = 0.5 * th, q = -half * half;
+        double pref = 1.0;
+        for (int k = 1; k <= lane && k <= KR_ECON_KMAX; ++k) pref *= half / (double)k;
         double sum = 1.0, term = 1.0;
-        for (int i = 1; i <= 24; ++i) { term *= q / ((double)i * (double)(k + i)); sum += term; }
-        c[k] = (k ? 2.0 : 1.0) * pref * sum;
+        for (int i = 1; i <= 14; ++i) { term *= q / ((double)i * (double)(lane + i)); sum += term; }
+        c[lane] = (lane <= KR_ECON_KMAX) ? (lane ? 2.0 : 1.0) * pref * sum : 0.0;
     }
-    int m = 0;
+    __syncthreads();
     double tail = 0.0;
-    for (int k = KR_ECON_KMAX; k >= 2; --k) {   // smallest m >= 1 with sum_{k > m} |c_k| <= tol
-        tail += fabs(c[k]);
-        if (tail > tol) { m = k; break; }
+    for (int k = KR_ECON_KMAX; k >= lane && k >= 0; --k) tail += fabs(c[k]);   // sum_{k >= lane} |c_k|
+    const unsigned long long over = __ballot(lane >= 2 && lane <= KR_ECON_KMAX && tail > tol);
+    const int m = over ? (63 - __builtin_clzll(over)) : 1;   // smallest m >= 1 with sum_{k > m} |c_k| <= tol
+    if (m > 29) {
+        if (lane < KR_ECON_W) row[lane] = 0.0;
+        return;
     }
-    if (m == 0) m = 1;
-    if (m > 29) return;
-    double acc[30], tp[30], tc[30];   // a_j (before the theta^-j), T_{k-1}, T_k
-    for (int j = 0; j < 30; ++j) { acc[j] = 0.0; tp[j] = 0.0; tc[j] = 0.0; }
-    tc[0] = 1.0;   // T_0
+    double acc = 0.0, tp = 0.0, tc = (lane == 0) ? 1.0 : 0.0;   // lane j: a_j (before theta^-j), t_{k-1,j}, t_{k,j}
     for (int k = 0; k <= m; ++k) {
-        for (int j = k & 1; j <= k; j += 2) acc[j] += ((((k - j) >> 1) & 1) ? -1.0 : 1.0) * c[k] * tc[j];
-        // T_{k+1} = 2 x T_k - T_{k-1}
-        double tn[30];
-        for (int j = 0; j < 30; ++j) tn[j] = ((j > 0) ? 2.0 * tc[j - 1] : 0.0) - tp[j];
-        if (k == 0) { for (int j = 0; j < 30; ++j) tn[j] = 0.0; tn[1] = 1.0; }   // T_1 = x
-        for (int j = 0; j < 30; ++j) { tp[j] = tc[j]; tc[j] = tn[j]; }
+        if (lane <= k && (((k - lane) & 1) == 0)) acc += ((((k - lane) >> 1) & 1) ? -1.0 : 1.0) * c[k] * tc;
+        const double up = __shfl_up(tc, 1, 64);
+        double tn = ((lane > 0) ? 2.0 * up : 0.0) - tp;   // T_{k+1} = 2 x T_k - T_{k-1}
+        if (k == 0) tn = (lane == 1) ? 1.0 : 0.0;         // T_1 = x
+        tp = tc; tc = tn;
     }
     double ti = 1.0;
-    for (int j = 0; j <= m; ++j) { acc[j] *= ti; ti /= th; }
-    row[0] = acc[0];
-    row[1] = acc[1];
-    for (int j = 2; j <= m; ++j) row[j] = acc[j] / acc[j - 1];
-    row[30] = th;
-    row[31] = (double)m;
+    for (int j = 0; j < lane && j < 30; ++j) ti /= th;
+    const double aj = acc * ti, ajm1 = __shfl_up(aj, 1, 64);
+    if (lane < KR_ECON_W) {
+        double v = 0.0;
+        if (lane <= 1) v = aj;
+        else if (lane <= m) v = aj / ajm1;
+        else if (lane == 30) v = th;
+        else if (lane == 31) v = (double)m;
+        row[lane] = v;
+    }
 }
 
 __global__ void kr_tau_kernel(const double2 *tgt, const double2 *psi, double2 *tau, int N, int K) {
@@ -1314,6 +1320,14 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         const bool mf_apply = h->NP == 64 && h->use_mfma && (mfa == 1 || (mfa == -1 && h->KT >= 2)) && (h->Kp % 2 == 0) &&
                               (h->G == 1 || h->KT % 2 == 0);
         a.u_layout = mf_apply ? 1 : 0;
+        if (h->econ && h->NP == 64) {   // economized polynomial of every step (the pulses are known exactly: margin = rounding only;
+                                        // smaller N: building the rows costs what the saved product gains -- C2 +6 us per sweep)
+            const int rows = h->G * h->cfg.NT;
+            hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->G, h->cfg.NT, h->cfg.L,
+                               h->tol, 1.0 + 1e-9, h->econ_d);
+            HIPCHK(h, hipGetLastError());
+            a.econ = h->econ_d;
+        }
         HIPCHK(h, h->launch(h->LMAXv, std::min(h->KT, 4), 2, h->cfg.NT * h->G, h->stream, &a));
         if (mf_apply) {
             int kt_a = (h->KT % 2 == 0) ? std::min(h->KT, 4) : 2;
@@ -1369,7 +1383,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
     if (h->econ) {   // rows of the economized step polynomial from this sweep's guess pulses (device-resident pulses included)
         const int rows = h->G * h->cfg.NT;
-        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, h->stream, eps_guess_dev, h->dt_d, h->nrm_d, h->G, h->cfg.NT, h->cfg.L,
+        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_guess_dev, h->dt_d, h->nrm_d, h->G, h->cfg.NT, h->cfg.L,
                            h->tol, 1.01, h->econ_d);
         HIPCHK(h, hipGetLastError());
         a.econ = h->econ_d;
