@@ -343,6 +343,18 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #ifndef KR_SLOT_GRANULES
 #define KR_SLOT_GRANULES (LMAX)
 #endif
+// One replica of the mailbox per XCD: every workgroup stores its slot into all 8 replicas (one store instruction, 8 x L active
+// lanes), the polling wave reads the replica of the XCD it runs on (HW_REG_XCC_ID) -- 32 pollers per 4 KB of slots instead of 256.
+// A poll pass with every slot present took 0.84 us at C3 (tools/exchange_arrivals.py; 2-4 x the idle load latency: 256 CUs pull
+// the same 4 KB through the few memory channels that hold them); in isolation (tools/ubench/exchange.hip, P = 256, uncached
+// mailbox) 1.93 -> 1.60 us per exchange with replicas 64 KB apart, 1.70 with replicas 4 KB + 256 B apart.  Any replica holds
+// every partial sum, so which one a wave reads changes timing only.
+// (KR_MAIL_REPLICAS, KR_MAIL_RSTRIDE: kr_common.h)
+__device__ __forceinline__ unsigned kr_xcc_id() {
+    unsigned id;
+    asm("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    return id & (KR_MAIL_REPLICAS - 1);
+}
 #ifndef KR_POLL_SLEEP
 #define KR_POLL_SLEEP 0  // measured at P = 256: 0 -> 7.48 ms per update sweep, 1 -> 7.55, 4 -> 7.60, 16 -> 7.78
 #endif
@@ -413,6 +425,7 @@ template <> struct KrPollLsb<4> {   // slot = two 16-byte words {d0, d1}, {d2, d
 template <int LMAX>
 __device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par, const unsigned phase, const int lane, double (&tot)[LMAX]) {
     static_assert(LMAX == 2 || LMAX == 4, "slot = LMAX doubles in 16-byte words");
+    static_assert(LMAX <= 4, "publishing lanes: 4 per replica");
     constexpr int WORDS = KrPollLsb<LMAX>::WORDS;
     const int L = a.L, P = a.P;
     bool ok = true;
@@ -420,7 +433,7 @@ __device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par
     for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
     for (int q0 = 0; q0 < P; q0 += 64 * KR_POLL_CHUNKS) {
         const int left = P - q0, nch = (left + 63) >> 6;   // wave-uniform
-        const unsigned long long *sbase = a.mail + ((size_t)par * P + q0) * KR_SLOT_GRANULES;
+        const unsigned long long *sbase = a.mail + ((size_t)par * KR_MAIL_REPLICAS + kr_xcc_id()) * KR_MAIL_RSTRIDE + (size_t)q0 * KR_SLOT_GRANULES;
         kr_v4u g[KR_POLL_CHUNKS][WORDS];
         KrPollLsb<LMAX>::pass(sbase, (unsigned)lane * (8u * LMAX), nch, g);
 #pragma unroll
@@ -500,11 +513,11 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             }
             tot1[l] = v;
         }
-        if (lane < L) {
+        if (lane < 4 * KR_MAIL_REPLICAS && (lane & 3) < L) {   // lane = 4 * replica + l
             double v = 0.0;
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) if (l == lane) v = tot1[l];
-            const unsigned long long *dst = a.mail + ((size_t)lpar * P + wg) * KR_SLOT_GRANULES + lane;
+            for (int l = 0; l < LMAX; ++l) if (l == (lane & 3)) v = tot1[l];
+            const unsigned long long *dst = a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + (lane >> 2)) * KR_MAIL_RSTRIDE + (size_t)wg * KR_SLOT_GRANULES + (lane & 3);
             const unsigned long long val = kr_slot_bits(v, phase);
             asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
         }
@@ -545,12 +558,12 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         }
         if (!(P == 1 && a.world == 1)) {
             // 2. publish this workgroup's partial
-            kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)lpar * P + wg) * KR_SLOT_GRANULES);
-            if (SCHED == 0 && lane < L) {
+            if (SCHED == 0 && lane < 4 * KR_MAIL_REPLICAS && (lane & 3) < L) {   // lane = 4 * replica + l
+                kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + (lane >> 2)) * KR_MAIL_RSTRIDE + (size_t)wg * KR_SLOT_GRANULES);
                 double v = 0.0;
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l) if (l == lane) v = tot[l];
-                __hip_atomic_store(slot + lane, kr_slot_bits(v, phase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int l = 0; l < LMAX; ++l) if (l == (lane & 3)) v = tot[l];
+                __hip_atomic_store(slot + (lane & 3), kr_slot_bits(v, phase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #ifdef KR_ARRIVALS  // diagnostic build: when did every workgroup publish / complete two exchanges in the middle of the sweep
             const bool arr = a.debug != nullptr && lane == 0 && (n == a.NT / 2 || n == a.NT / 2 + 1);

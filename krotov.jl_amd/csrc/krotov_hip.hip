@@ -924,7 +924,9 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
     CHK(hipMemset(h->psiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->chiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->gint_d, 0, std::max(L, KR_LMAX_CAP) * sizeof(double)));
-    h->mail_words = (size_t)2 * h->P * 16 + 64 * 4;  // room for 128-B slots; tail: a poll pass reads whole 64-slot chunks (kr_poll_pass)
+    h->mail_words = (size_t)2 * KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE + 64 * 4;  // 2 buffers x 8 replicas (one per XCD) x 64 KB (kr_exchange); tail: a poll pass
+                                                                               // reads whole 64-slot chunks (kr_poll_pass)
+    if ((size_t)h->P * 4 > KR_MAIL_RSTRIDE) { fail(h, KR_ERR_UNSUPPORTED, "%d workgroups do not fit one mailbox replica", h->P); return bail(KR_ERR_UNSUPPORTED); }
     CHK(alloc_mailbox(h, &h->mail_d, h->mail_words, h->P));
     CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
     CHK(dalloc(&h->debug_d, 8 + 8 * 1024));   // 8 phase stamps + per-workgroup arrival stamps of diagnostic builds (KR_ARRIVALS)

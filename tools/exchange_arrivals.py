@@ -38,6 +38,12 @@ for e in range(2):
              np.median(done - pub) * tick, np.median(passes) + 1, passes.max() + 1))
     xcd = np.arange(P) % 8
     print("   publish offset by XCD (ns, median): " + " ".join("%4.0f" % ((np.median(pub[xcd == x]) - t0) * tick) for x in range(8)))
+    print("   window work by XCD (ns, median):        " + " ".join("%4.0f" % (np.median((wend - pub)[xcd == x]) * tick) for x in range(8)))
+    print("   poll (window end -> done) by XCD (ns):   " + " ".join("%4.0f" % (np.median((done - wend)[xcd == x]) * tick) for x in range(8)))
+    print("   poll passes by XCD (median):             " + " ".join("%4.1f" % (np.median(passes[xcd == x]) + 1) for x in range(8)))
     print("   completion offset by XCD (ns, median): " + " ".join("%4.0f" % ((np.median(done[xcd == x]) - t0) * tick) for x in range(8)))
 if a[:, 1, 0].any():
+    xcd = np.arange(P) % 8
+    print("own cycle outside the exchange (done of exchange 0 -> publish of exchange 1) by XCD (ns, median): "
+          + " ".join("%4.0f" % (np.median((a[:, 1, 0] - a[:, 0, 2])[xcd == x]) * tick) for x in range(8)))
     print("step length (publish to publish): median %.0f ns" % (np.median(a[:, 1, 0] - a[:, 0, 0]) * tick))

@@ -14,6 +14,7 @@
 
 typedef unsigned long long u64;
 #define LQ 4  // granules per slot (L = 2 doubles)
+#define MAILBYTES (2 * 8 * 65536 + 65536)
 
 __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -265,6 +266,19 @@ __global__ __launch_bounds__(256) void exch16(int variant, int split, u64 *mail,
                 if (!done) ok = gather_lsb(buf, P, phase, tot, lane);
             }
         } else
+        if (variant == 14 || variant == 15) {   // one-bit validity + one replica of the mailbox per XCD (14: replicas 4 KB + 256 B apart, 15: 64 KB apart)
+            const unsigned phase = ((tag + 1u) >> 1) & 1u;
+            const size_t rstride = (variant == 14) ? (4096 + 256) / 8 : 65536 / 8;
+            unsigned id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+            if (wave == 0 && lane < 8) {
+                const u64 b0 = ((u64)__double_as_longlong(v0) & ~1ull) | phase, b1 = ((u64)__double_as_longlong(v1) & ~1ull) | phase;
+                u4 q; q.x = (unsigned)b0; q.y = (unsigned)(b0 >> 32); q.z = (unsigned)b1; q.w = (unsigned)(b1 >> 32);
+                const u64 *dst = mail + (size_t)par * 8 * rstride + (size_t)lane * rstride + (size_t)wg * 2;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(q) : "memory");
+            }
+            if (wave == 0) ok = gather_lsb(mail + (size_t)par * 8 * rstride + (size_t)(id & 7) * rstride, P, phase, tot, lane);
+        } else
         if (variant == 11) {
             const unsigned phase = ((tag + 1u) >> 1) & 1u;  // first use of either buffer expects 1: zeroed memory is invalid
             if (wave == 0 && lane == 0) {
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(256) void exch16(int variant, int split, u64 *mail,
             }
         } else
         if (wave == 0) publish<__HIP_MEMORY_SCOPE_AGENT>(mail + ((size_t)par * P + wg) * LQ, tag, v0, v1, lane);
-        if (variant == 11 || variant == 12 || variant == 13) {
+        if (variant >= 11) {
         } else
         if (variant == 9) {
             if (wave == 0) ok = gather16_asm<1>(mail + (size_t)par * 10240, P, tag, tot, lane);
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(256) void exch16(int variant, int split, u64 *mail,
         if (variant != 6 && wave != 0) { tot[0] = tot[1] = 0; }
         if (!ok) { if (threadIdx.x == 0) atomicAdd(fail, 1u); break; }
         acc0 += tot[0]; acc1 += tot[1];
-        if (variant < 12) for (int w = 0; w < work; ++w) __builtin_amdgcn_s_sleep(1);
+        if (variant < 12 || variant > 13) for (int w = 0; w < work; ++w) __builtin_amdgcn_s_sleep(1);
         else for (int w = 0; w < 16; ++w) __builtin_amdgcn_s_sleep(1);  // the rest of the step
     }
     const u64 t1 = wall_clock64();
@@ -376,16 +390,16 @@ int main(int argc, char **argv) {
     const int only = argc > 3 ? atoi(argv[3]) : -1;
     u64 *mail, *mailB, *cyc; double *out; unsigned *xcc, *fail;
     // MAILMEM=1: uncached allocation (what the library uses with >= 64 pollers)
-    if (getenv("MAILMEM") && atoi(getenv("MAILMEM")) == 1) { if (hipExtMallocWithFlags((void **)&mail, 2 * 10240 * 8, hipDeviceMallocUncached) != hipSuccess) { printf("uncached alloc failed\n"); return 1; } }
-    else hipMalloc(&mail, 2 * 10240 * 8);
+    if (getenv("MAILMEM") && atoi(getenv("MAILMEM")) == 1) { if (hipExtMallocWithFlags((void **)&mail, MAILBYTES, hipDeviceMallocUncached) != hipSuccess) { printf("uncached alloc failed\n"); return 1; } }
+    else hipMalloc(&mail, MAILBYTES);
     hipMalloc(&mailB, 2 * 8 * LQ * 8);
     hipMalloc(&out, 256 * 2 * 8); hipMalloc(&cyc, 256 * 8); hipMalloc(&xcc, 256 * 4); hipMalloc(&fail, 4);
     for (int P : {8, 64, 256}) {
         for (int work : {0, 32, 64}) {
-            for (int variant = 0; variant < 14; ++variant) {
+            for (int variant = 0; variant < 16; ++variant) {
                 if (variant == 1 && P > 8) continue;
                 if (only >= 0 && variant < only) continue;  // sc0 loads hit the (stale) L1: never completes
-                hipMemset(mail, 0, 2 * 10240 * 8); hipMemset(mailB, 0, 2 * 8 * LQ * 8);
+                hipMemset(mail, 0, MAILBYTES); hipMemset(mailB, 0, 2 * 8 * LQ * 8);
                 hipMemset(fail, 0, 4);
                 if (variant >= 4) hipLaunchKernelGGL(exch16, dim3(P), dim3(variant == 6 ? 256 : 64), 0, 0, variant, split, mail, out, cyc, P, iters, work, fail);
                 else hipLaunchKernelGGL(exch, dim3(P), dim3(64), 0, 0, variant, mail, mailB, out, cyc, xcc, P, iters, work, fail);
