@@ -350,6 +350,12 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 // mailbox) 1.93 -> 1.60 us per exchange with replicas 64 KB apart, 1.70 with replicas 4 KB + 256 B apart.  Any replica holds
 // every partial sum, so which one a wave reads changes timing only.
 // (KR_MAIL_REPLICAS, KR_MAIL_RSTRIDE: kr_common.h)
+// A wave-uniform pointer the compiler may hold in vector registers, for the "s" operand of an asm statement
+__device__ __forceinline__ const unsigned long long *kr_uniform_ptr(const unsigned long long *p) {
+    const unsigned long long v = (unsigned long long)(size_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const unsigned long long *)(size_t)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ unsigned kr_xcc_id() {
     unsigned id;
     asm("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
@@ -433,7 +439,7 @@ __device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par
     for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
     for (int q0 = 0; q0 < P; q0 += 64 * KR_POLL_CHUNKS) {
         const int left = P - q0, nch = (left + 63) >> 6;   // wave-uniform
-        const unsigned long long *sbase = a.mail + ((size_t)par * KR_MAIL_REPLICAS + kr_xcc_id()) * KR_MAIL_RSTRIDE + (size_t)q0 * KR_SLOT_GRANULES;
+        const unsigned long long *sbase = kr_uniform_ptr(a.mail + ((size_t)par * KR_MAIL_REPLICAS + kr_xcc_id()) * KR_MAIL_RSTRIDE + (size_t)q0 * KR_SLOT_GRANULES);
         kr_v4u g[KR_POLL_CHUNKS][WORDS];
         KrPollLsb<LMAX>::pass(sbase, (unsigned)lane * (8u * LMAX), nch, g);
 #pragma unroll
@@ -458,6 +464,61 @@ __device__ __forceinline__ unsigned long long kr_slot_bits(const double v, const
     return ((unsigned long long)__double_as_longlong(v) & ~1ull) | (unsigned long long)phase;
 }
 
+// EARLY pass of the polling wave (update kernels with window work, one GPU): issued as LDS-DMA in the middle of the window work
+// -- global_load_lds_dwordx4: no result registers to keep live across the rest of the window --, checked when the window work is
+// done.  The workgroups that publish LAST set the pace of a step: such a workgroup spent window (0.84 us) + one pass (0.76 us)
+// after its publish although every other slot was visible long before (tools/exchange_arrivals.py); with the pass in flight during
+// the second half of the window it is done ~0.3 us earlier.  This workgroup's own slot comes from registers (the value it has just
+// published: its store may not be visible yet).  Issued right AFTER the publish the pass never hit (0 of 256 workgroups: the last
+// workgroups of a step are a whole XCD publishing within 0.2 us of each other, and a store takes ~0.7 us to become visible).
+// A workgroup whose early pass misses polls as before.
+// The LDS image mirrors the replica's buffer byte for byte (1 KB pieces: scalar base, lane offset, M0 = LDS address of the piece).
+template <int LMAX>
+__device__ __forceinline__ void kr_poll_issue_lds(const unsigned long long *sbase, const int pieces, unsigned long long *spoll, const int lane) {
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void *)spoll;
+    const unsigned voff = (unsigned)lane * 16u;
+    for (int c = 0; c < pieces; ++c) {   // wave-uniform trip count
+        unsigned keep;
+        const unsigned long long *sb = kr_uniform_ptr(sbase + 128 * c);
+        const unsigned ld = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds + 1024u * (unsigned)c));
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sb), "s"(ld) : "memory");
+    }
+}
+// Check of the early pass: slot q of lane = lane + 64 c from the LDS image; `own` (this workgroup's slot index) comes from `mine_bits`.
+template <int LMAX>
+__device__ __forceinline__ bool kr_poll_check_lds(const KrSweepArgs &a, const unsigned long long *spoll, const unsigned phase, const int lane,
+                                                  const int own, const unsigned long long (&mine_bits)[LMAX], double (&tot)[LMAX]) {
+    const int L = a.L, P = a.P;
+    bool ok = true;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
+    for (int q = lane; q < P; q += 64) {   // at most KR_POLL_CHUNKS trips (the caller checks P)
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < L) {
+                const unsigned long long g = (q == own) ? mine_bits[l] : spoll[(size_t)q * LMAX + l];
+                ok = ok & (((unsigned)g & 1u) == phase);
+                tot[l] += __longlong_as_double((long long)g);
+            }
+        }
+    }
+    return ok;
+}
+
+// What kr_exchange hands to the window work: the window calls it ONCE, on every wave, about half-way through; on the polling wave it
+// issues the early poll pass, on the others nothing.
+template <int LMAX>
+struct KrMidPoll {
+    const unsigned long long *sbase;
+    unsigned long long *spoll;
+    int pieces, lane;
+    bool armed, issued;
+    __device__ __forceinline__ void operator()() {
+        if (armed) { kr_poll_issue_lds<LMAX>(sbase, pieces, spoll, lane); issued = true; }
+    }
+};
+
 // One wave gathers all P slots of buffer `par` until every slot carries `phase`; tot = sum over the slots, same order as in
 // kr_exchange.  Bounded; false = gave up (the caller's wave 0 flags it).
 template <int LMAX>
@@ -475,7 +536,9 @@ __device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int 
     return true;
 }
 
-struct KrNoWork { __device__ __forceinline__ void operator()() const {} };
+struct KrNoWork { template <class M> __device__ __forceinline__ void operator()(M &) const {} };
+template <class F> struct KrIsNoWork { static constexpr bool value = false; };
+template <> struct KrIsNoWork<KrNoWork> { static constexpr bool value = true; };
 
 // `work` is called exactly once by every wave while the partial sums travel (after the publishing store, before the
 // polling wave starts to poll): barrier-free work that does not depend on the total (kr_sweep_update, HERM path).
@@ -493,6 +556,9 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
     // mailbox inside the GPU: buffer and phase from the step index of THIS launch (the mailbox is zeroed in front of it)
     const int lpar = n & 1;
     const unsigned phase = (((unsigned)n >> 1) & 1u) ^ 1u;
+
+    constexpr bool EARLY = !KrIsNoWork<F>::value;   // a window exists: overlap the first poll pass with it
+    __shared__ __attribute__((aligned(16))) unsigned long long spoll[EARLY ? 64 * KR_POLL_CHUNKS * LMAX : 2];
 
     // 1. the ROWS row owners of the workgroup deposit their partial sums
     if (writer) {
@@ -522,7 +588,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
         }
     }
-    if (wave != 0) work();
+    if (wave != 0) { KrMidPoll<LMAX> nomid{nullptr, nullptr, 0, 0, false, false}; work(nomid); }
     if (wave == 2 && a.world > 1 && wg == 0) {
         // 4a. inter-GPU hop, sending side: wave 2 of workgroup 0 gathers the slots as well and stores the GPU total into
         //     every rank's xmail (slot = this rank).  Its stores cross xGMI; a wave that polls after storing waits for
@@ -569,17 +635,28 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             const bool arr = a.debug != nullptr && lane == 0 && (n == a.NT / 2 || n == a.NT / 2 + 1);
             if (arr) a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2)] = kr_realtime();
 #endif
-            work();
+            const int pieces = (P * 8 * LMAX + 1023) >> 10;
+            const bool early = EARLY && SCHED == 0 && a.world == 1 && P <= 64 * KR_POLL_CHUNKS && P > 1;
+            unsigned long long mine_bits[LMAX];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) mine_bits[l] = kr_slot_bits(tot[l], phase);
+            KrMidPoll<LMAX> mid{a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + kr_xcc_id()) * KR_MAIL_RSTRIDE, spoll, pieces, lane, early, false};
+            work(mid);
 #ifdef KR_ARRIVALS
             if (arr) a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 1] = kr_realtime();
 #endif
+            bool done_early = false;
+            if (mid.issued) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                done_early = __all(kr_poll_check_lds<LMAX>(a, spoll, phase, lane, wg, mine_bits, tot));
+            }
             if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
             // 3. gather all P slots (lane handles slots lane, lane+64, ...), bounded spin.  With peers on other GPUs only
             //    the forwarding wave gathers them (one poller instead of P: the stores become visible sooner); everybody
             //    else waits for the grand total in xmail, which includes this GPU's own contribution.
             const unsigned long long t0 = kr_realtime();
             unsigned spins = 0;
-            for (; a.world == 1;) {
+            for (; a.world == 1 && !done_early;) {
                 const bool ok = kr_poll_pass<LMAX>(a, lpar, phase, lane, tot);
                 if (__all(ok)) break;
                 if ((++spins & 63u) == 0u) {
@@ -601,7 +678,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(tot[l]);
             }
 #ifdef KR_ARRIVALS
-            if (arr) { a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 2] = kr_realtime(); a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 3] = spins; }
+            if (arr) { a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 2] = kr_realtime(); a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 3] = spins + (done_early ? 100u : 0u); }
 #endif
 
             // 4. inter-GPU hop, receiving side (the sending side is wave 2 of workgroup 0, above): every workgroup polls
@@ -652,7 +729,8 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(gt[l]);  // same tree on every GPU: bitwise identical totals
             }
         } else {
-            work();
+            KrMidPoll<LMAX> nomid{nullptr, nullptr, 0, 0, false, false};
+            work(nomid);
         }
         if (lane == 0) {
 #pragma unroll
@@ -850,9 +928,10 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                     if (l < L && ((gx.present >> l) & 1u)) part[l] += clr[q][l] * pim[q] - cli[q][l] * pr[q];
             }
         }
-        auto window = [&]() {
+        auto window = [&](auto &mid) {
             if (HERM) {
                 form_and_apply();
+                mid();   // (polling wave: early poll pass, kr_exchange)
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
 #pragma unroll

@@ -26,7 +26,10 @@ a = eng.debug_arrivals(P).astype(np.int64)
 print(cfg, {k: info[k] for k in ("workgroups", "exchange_poll_delay", "hermitian_controls_path", "matrix_core_sweep")})
 tick = 10.0  # ns
 for e in range(2):
-    pub, wend, done, passes = a[:, e, 0], a[:, e, 1], a[:, e, 2], a[:, e, 3]
+    pub, wend, done, passes = a[:, e, 0], a[:, e, 1], a[:, e, 2], a[:, e, 3].copy()
+    early = passes >= 100
+    passes[early] -= 101   # an early hit needs no register pass
+    print("   early pass (LDS-DMA at publish time) hit in %d of %d workgroups; by XCD: %s" % (early.sum(), P, " ".join("%2d" % early[np.arange(P) % 8 == x].sum() for x in range(8))))
     if not pub.any():
         print("no arrival stamps: library not built with -DKR_ARRIVALS?")
         break
