@@ -472,6 +472,8 @@ __device__ __forceinline__ unsigned long long kr_slot_bits(const double v, const
 // published: its store may not be visible yet).  Issued right AFTER the publish the pass never hit (0 of 256 workgroups: the last
 // workgroups of a step are a whole XCD publishing within 0.2 us of each other, and a store takes ~0.7 us to become visible).
 // A workgroup whose early pass misses polls as before.
+// MEASURED AND COMPILED OUT (KR_EARLY_POLL = 0): in the kernel the early pass hits in 170-200 of 256 workgroups per step, yet
+// the step grows from 5.73 to 6.22 us at C3 (same box, wave 0 publishing); kept for the record and the diagnostics build.
 // The LDS image mirrors the replica's buffer byte for byte (1 KB pieces: scalar base, lane offset, M0 = LDS address of the piece).
 template <int LMAX>
 __device__ __forceinline__ void kr_poll_issue_lds(const unsigned long long *sbase, const int pieces, unsigned long long *spoll, const int lane) {
@@ -537,6 +539,9 @@ __device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int 
 }
 
 struct KrNoWork { template <class M> __device__ __forceinline__ void operator()(M &) const {} };
+#ifndef KR_EARLY_POLL
+#define KR_EARLY_POLL 0
+#endif
 template <class F> struct KrIsNoWork { static constexpr bool value = false; };
 template <> struct KrIsNoWork<KrNoWork> { static constexpr bool value = true; };
 
@@ -931,7 +936,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         auto window = [&](auto &mid) {
             if (HERM) {
                 form_and_apply();
-                mid();   // (polling wave: early poll pass, kr_exchange)
+                if (KR_EARLY_POLL) mid();   // (polling wave: early poll pass, kr_exchange)
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
 #pragma unroll
