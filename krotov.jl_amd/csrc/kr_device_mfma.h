@@ -487,40 +487,51 @@ __global__ __launch_bounds__(256, 1) void kr_mf_apply_sweep(const KrSweepArgs a)
         for (int c = 0; c < CH; ++c)
             if (m_ok[c]) a.store[(size_t)slot0 * slab + tile_base + lane + 64 * c] = a.init[tile_base + lane + 64 * c];
     }
-    // A operands of the first step
-    double2 un[16];
+    // A operands: TWO steps in flight (ua, ub) next to the set in use (three: C4 1.88 -> 1.85 ms per sweep, K = 512 1.37 -> 1.41).  With one step in flight a step took the load latency
+    // plus the transfer of the 64 KB (1.92 us at two tiles against ~0.5 us of MFMA work): the loads of step n + 1 were only
+    // issued once those of step n had arrived.
+    double2 ua[16], ub[16];
     {
         const int n0 = (a.dir > 0) ? 0 : (NT - 1);
         const double2 *U = Umf + (size_t)n0 * 4096 + (size_t)wave * 1024 + lane;
 #pragma unroll
-        for (int sl = 0; sl < 16; ++sl) un[sl] = U[sl * 64];
+        for (int sl = 0; sl < 16; ++sl) ua[sl] = U[sl * 64];
+        if (NT > 1) {
+            const int n1 = (a.dir > 0) ? 1 : (NT - 2);
+            const double2 *U1 = Umf + (size_t)n1 * 4096 + (size_t)wave * 1024 + lane;
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) ub[sl] = U1[sl * 64];
+        }
     }
     __syncthreads();
     int cur = 0;
     double psi[TILES];
-    for (int step = 0; step < NT; ++step) {
-        const int n = (a.dir > 0) ? step : (NT - 1 - step);
-        double Ar[16], Ai[16];
-#pragma unroll
-        for (int sl = 0; sl < 16; ++sl) { Ar[sl] = un[sl].x; Ai[sl] = un[sl].y; }
-        if (step + 1 < NT) {   // operands of the next step: they land while this step's round runs
-            const int n1 = (a.dir > 0) ? (step + 1) : (NT - 2 - step);
-            const double2 *U = Umf + (size_t)n1 * 4096 + (size_t)wave * 1024 + lane;
-#pragma unroll
-            for (int sl = 0; sl < 16; ++sl) un[sl] = U[sl * 64];
-        }
-        kr_mf_apply<TILES>(Ar, Ai, &sx[cur][0][0], boff, kb0, psi);
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) kr_mf_put(sx[cur ^ 1][t], doff, zoff, zs, psi[t]);
-        __syncthreads();
-        cur ^= 1;
-        if (memwave && a.store) {
-            const int slot = (a.dir > 0) ? (n + 1) : n;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (m_ok[c]) a.store[(size_t)slot * slab + tile_base + lane + 64 * c] = make_double2((&sx[cur][0][0])[m_pos[c]].y, (&sx[cur][0][0])[m_pos[c] + 1].y);
-        }
+#define KR_MF_APPLY_STEP(step_, un_)                                                                                   \
+    {                                                                                                                  \
+        const int n = (a.dir > 0) ? (step_) : (NT - 1 - (step_));                                                      \
+        double Ar[16], Ai[16];                                                                                         \
+        _Pragma("unroll") for (int sl = 0; sl < 16; ++sl) { Ar[sl] = un_[sl].x; Ai[sl] = un_[sl].y; }                  \
+        if ((step_) + 2 < NT) {   /* operands of the step after next */                                                \
+            const int n2 = (a.dir > 0) ? ((step_) + 2) : (NT - 3 - (step_));                                           \
+            const double2 *U = Umf + (size_t)n2 * 4096 + (size_t)wave * 1024 + lane;                                   \
+            _Pragma("unroll") for (int sl = 0; sl < 16; ++sl) un_[sl] = U[sl * 64];                                    \
+        }                                                                                                              \
+        kr_mf_apply<TILES>(Ar, Ai, &sx[cur][0][0], boff, kb0, psi);                                                    \
+        _Pragma("unroll") for (int t = 0; t < TILES; ++t) kr_mf_put(sx[cur ^ 1][t], doff, zoff, zs, psi[t]);           \
+        __syncthreads();                                                                                               \
+        cur ^= 1;                                                                                                      \
+        if (memwave && a.store) {                                                                                      \
+            const int slot = (a.dir > 0) ? (n + 1) : n;                                                                \
+            _Pragma("unroll") for (int c = 0; c < CH; ++c)                                                             \
+                if (m_ok[c]) a.store[(size_t)slot * slab + tile_base + lane + 64 * c] =                                \
+                    make_double2((&sx[cur][0][0])[m_pos[c]].y, (&sx[cur][0][0])[m_pos[c] + 1].y);                      \
+        }                                                                                                              \
     }
+    for (int step = 0; step < NT; step += 2) {
+        KR_MF_APPLY_STEP(step, ua)
+        if (step + 1 < NT) KR_MF_APPLY_STEP(step + 1, ub)
+    }
+#undef KR_MF_APPLY_STEP
     if (a.fin && memwave) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
