@@ -128,3 +128,31 @@ def test_rowsplit_hermitian_n100_substeps_across_refresh_boundaries(oracle_c):
     fw, it = _c_oracle(oracle_c)
     info = _iteration_vs_oracle(p, fw, it, sample_k=(0, 11), sample_n=(0, 32, 33, 96, 100), expect={"NP": 128})
     assert info["rowsplit_R"] > 1
+
+
+@pytest.mark.parametrize("shape", ["C3", "D:64,1000,512,2", "D:64,1000,128,2", "D:16,1000,300,1"])
+def test_soak_many_iterations_reproducible(shape):
+    """The per-step exchange validates a slot with ONE bit (kr_device.h) and every workgroup forms the pulse update for itself: a
+    stale or torn slot would not raise an error, it would change a sum on SOME workgroups -- timing-dependent, so two runs would
+    differ.  25 chained iterations (25 000 exchanges per run, every kernel family of the register-resident sweeps) on two
+    independent engines must give bitwise identical pulses and final states, the norms of all trajectories stay 1 (a workgroup
+    that propagated under a different pulse would not be caught by that, but a corrupted state would), and J_T falls
+    monotonically."""
+    p = wl.config(shape)
+    K, N = p["psi0"].shape
+    lam = np.full(len(p["lam"]), 0.05)
+    outs = []
+    for run in range(2):
+        with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+            eng.set_initial_states(p["psi0"])
+            psiT = eng.forward(p["eps"])
+            eps = p["eps"].copy()
+            J = [wl.chi_and_JT("ss", psiT, p["tgt"])[1]]
+            for it in range(25):
+                _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+                eps, _, psiT = eng.iteration(eps, chiT, p["S"], lam)
+                J.append(wl.chi_and_JT("ss", psiT, p["tgt"])[1])
+            assert np.max(np.abs(np.linalg.norm(psiT, axis=1) - 1.0)) < 1e-11
+            assert all(b < a for a, b in zip(J, J[1:])), J
+            outs.append((eps.copy(), psiT.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
