@@ -5,8 +5,11 @@
 // round).  Here workgroup (tile, rb) owns rows [rb*NR, (rb+1)*NR) of the generator: its block of H(eps) stays in
 // registers for all rounds of a step (NR = 64, NP = 256: 128 VGPRs per thread), the blocks of H0, H_l are streamed
 // once (known-pulse sweeps) or twice (update sweep) per STEP, and after every matvec round the R workgroups of a
-// trajectory all-gather the N new vector elements through a tagged mailbox (4 eight-byte granules
-// {tag32 | 32 bits} per complex element, agent-scope atomics, double-buffered by round parity, bounded spins).
+// trajectory all-gather the N new vector elements through a mailbox (one 16-byte word {re, im} per complex element, each double
+// validated by ONE bit -- its mantissa LSB = phase of the buffer's use, as in kr_exchange: a slot has one writer, written in order,
+// and the mailbox is zeroed in front of every launch; before: four {tag32 | 32 bits} granules per element, twice the poll bytes --,
+// double-buffered by round parity, bounded spins).  The owners put the SAME LSB-forced values into their own copy of the vector,
+// so that all R workgroups of a trajectory keep bitwise identical vectors.
 // The per-step global sum of the update integrands runs over all P = K*R workgroups with kr_exchange, each
 // workgroup contributing the rows it owns.
 //
@@ -50,12 +53,25 @@ __device__ __forceinline__ double kr_row_sum_wide(double v) {
 typedef unsigned int kr_u4 __attribute__((ext_vector_type(4)));
 
 struct KrGroupBox {
-    unsigned long long *base;  // this tile's mailbox: [2][NP][4] granules
+    unsigned long long *base;  // this tile's mailbox: [2][NP] elements of 16 B (2 x [NP][4] words are reserved per tile)
     unsigned tag_base;
     unsigned counter;
     unsigned long long tpoll, npass;  // diagnostics (a.debug): cycles spent polling and number of poll passes, wave 0
     bool local;  // all R workgroups of the tile run on ONE XCD (checked at kernel start): publish into that XCD's L2 only
 };
+
+// One poll pass of the all-gather: up to KR_POLL_CHUNKS elements per lane, 16 B each, sc1 loads; the loads and their wait are ONE asm
+// block (the compiler neither counts nor reorders asm loads).
+__device__ __forceinline__ void kr_poll_elems(const unsigned long long *p0, const unsigned long long *p1, const unsigned long long *p2,
+                                              const unsigned long long *p3, const int nch, kr_v4u (&g)[KR_POLL_CHUNKS]) {
+    if (nch > 2)
+        asm volatile(KR_PL(0, 4, 0) KR_PL(1, 5, 0) KR_PL(2, 6, 0) KR_PL(3, 7, 0) "s_waitcnt vmcnt(0)"
+                     : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+    else if (nch > 1)
+        asm volatile(KR_PL(0, 2, 0) KR_PL(1, 3, 0) "s_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]) : "v"(p0), "v"(p1) : "memory");
+    else
+        asm volatile(KR_PL(0, 1, 0) "s_waitcnt vmcnt(0)" : "=&v"(g[0]) : "v"(p0) : "memory");
+}
 
 // Publish this workgroup's NR new elements (row owners hold them) and gather the other blocks of the tile into
 // the LDS vector `dst` (padded layout).  Returns false on abort.  All threads of the workgroup call it.
@@ -64,8 +80,9 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
                                                 const int il, const double vr, const double vi, double2 *dst,
                                                 int *sflag) {
     const int tid = threadIdx.x;
-    const unsigned tag = box.tag_base + (++box.counter);
+    ++box.counter;
     const int par = box.counter & 1;
+    const unsigned phase = (((box.counter - 1u) >> 1) & 1u) ^ 1u;   // first use of either buffer expects 1: zeroed memory is invalid
     kr_gu64 *mb = (kr_gu64 *)(box.base + (size_t)par * NP * 4);
     // Row owners put their element into the LDS vector; after a barrier WAVE 1 publishes the whole block (16-byte asm
     // stores the compiler does not count: nobody waits for their acknowledgement) while wave 0, which therefore never
@@ -73,21 +90,20 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
     // from memory with its first poll pass (1.2-1.9 us against 0.75 us for a pass of loads alone).
     if (owner) {
         const int e = rb * NR + il;
-        dst[e + e / JS] = make_double2(vr, vi);
+        dst[e + e / JS] = make_double2(__longlong_as_double((long long)kr_slot_bits(vr, phase)), __longlong_as_double((long long)kr_slot_bits(vi, phase)));
     }
     __syncthreads();
     if ((tid >> 6) == 1 && (tid & 63) < NR) {
         const int e = rb * NR + (tid & 63);
         const double2 v = dst[e + e / JS];
         const unsigned long long br = (unsigned long long)__double_as_longlong(v.x), bi = (unsigned long long)__double_as_longlong(v.y);
-        kr_v4u wr, wi;  // one 16-byte store per component: {lo32, tag, hi32, tag} = two self-validating granules
-        wr.x = (unsigned)br; wr.y = tag; wr.z = (unsigned)(br >> 32); wr.w = tag;
-        wi.x = (unsigned)bi; wi.y = tag; wi.z = (unsigned)(bi >> 32); wi.w = tag;
-        const unsigned long long *pe = (const unsigned long long *)mb + 4 * e;
-        // local: sc0 stores stay in the XCD's L2, where the group's sc1 loads (which bypass only the vector L1) find them;
-        // otherwise sc1 stores write through to memory for readers on other XCDs
-        if (box.local) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0" :: "v"(pe), "v"(wr), "v"(wi) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(pe), "v"(wr), "v"(wi) : "memory");
+        kr_v4u w;  // one 16-byte store per element: {re, im}, each double validated by its LSB
+        w.x = (unsigned)br; w.y = (unsigned)(br >> 32); w.z = (unsigned)bi; w.w = (unsigned)(bi >> 32);
+        const unsigned long long *pe = (const unsigned long long *)mb + 2 * e;
+        // local: sc0 stores stay in the XCD's L2, where the group's sc1 loads (which bypass only the vector L1) find them
+        // (292 ns per hop against 626 across XCDs, tools/ubench/pingpong.hip); otherwise sc1 stores write through to memory
+        if (box.local) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(pe), "v"(w) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pe), "v"(w) : "memory");
     }
     // wave 0 gathers the NP - NR foreign elements: lane handles elements lane, lane + 64, ...; every load of a pass
     // is in flight before the first tag is looked at (no workgroup barrier inside the spin); 16-byte sc1 loads, the
@@ -105,17 +121,17 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
             el[c] = q;
         }
         const unsigned long long *mbc = (const unsigned long long *)mb;
-        kr_v4u g[KR_POLL_CHUNKS][2];
+        kr_v4u g[KR_POLL_CHUNKS];
         for (int w = 0; w < (box.local ? a.gather_delay_local : a.gather_delay); ++w) __builtin_amdgcn_s_sleep(2);
         const unsigned long long t0 = kr_realtime();
         const unsigned long long tm0 = a.debug ? __builtin_amdgcn_s_memtime() : 0;
         unsigned spins = 0;
         for (;;) {
             bool ok = true;
-            KrPoll<2>::pass(mbc + 4 * el[0], mbc + 4 * el[1], mbc + 4 * el[2], mbc + 4 * el[3], EC, g);
+            kr_poll_elems(mbc + 2 * el[0], mbc + 2 * el[1], mbc + 2 * el[2], mbc + 2 * el[3], EC, g);
 #pragma unroll
             for (int c = 0; c < EC; ++c)
-                ok = ok & (g[c][0].y == tag) & (g[c][0].w == tag) & (g[c][1].y == tag) & (g[c][1].w == tag);
+                ok = ok & ((g[c].x & 1u) == phase) & ((g[c].z & 1u) == phase);
             if (__all(ok)) break;
             if ((++spins & 63u) == 0u) {
                 const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -135,8 +151,8 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
                 if (lane + 64 * c < NP - NR) {
-                    const double re = __longlong_as_double((long long)(((unsigned long long)g[c][0].z << 32) | g[c][0].x));
-                    const double im = __longlong_as_double((long long)(((unsigned long long)g[c][1].z << 32) | g[c][1].x));
+                    const double re = __longlong_as_double((long long)(((unsigned long long)g[c].y << 32) | g[c].x));
+                    const double im = __longlong_as_double((long long)(((unsigned long long)g[c].w << 32) | g[c].z));
                     dst[el[c] + el[c] / JS] = make_double2(re, im);
                 }
             }

@@ -1106,10 +1106,9 @@ static int rowsplit_prelaunch(kr_handle *h, KrSweepArgs &a) {
     if ((long long)h->cfg.NT * (KR_MAX_ORDER + 2) * 4 >= (1ll << 24))
         return fail(h, KR_ERR_UNSUPPORTED, "row-split kernels: N_T = %d too large for the mailbox tag space (set KROTOV_HIP_ROWSPLIT=0)", h->cfg.NT);
     h->launch_id = (h->launch_id + 1) & 0xffu;
-    if (h->launch_id == 0) {
-        HIPCHK(h, hipMemsetAsync(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long), h->stream));
-        h->launch_id = 1;
-    }
+    if (h->launch_id == 0) h->launch_id = 1;
+    // the all-gather validates its elements with one bit per double whose phase starts at 1 in every launch: start from zeros
+    HIPCHK(h, hipMemsetAsync(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long), h->stream));
     a.epoch_base2 = h->launch_id << 24;
     return KR_OK;   // (the status words are sticky: only check_status clears them)
 }
