@@ -1095,7 +1095,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     // row-split all-gather: polling starts 9 x 128 cycles (0.48 us) after the block was handed to the publishing wave;
     // measured at C5 (forward sweep, us per step): 0 -> 32.4, 4 -> 31.5, 8 -> 30.6, 10 -> 30.4, 12 -> 31.0, 16 -> 32.8, 20 -> 34.7
     a.gather_delay = env_int("KROTOV_HIP_GATHER_DELAY", 9);
-    a.gather_delay_local = env_int("KROTOV_HIP_GATHER_DELAY_LOCAL", 4);  // C5 forward sweep: 0 -> 26.4, 4 -> 25.8, 6 -> 25.5, 8 -> 26.1 us per step
+    a.gather_delay_local = env_int("KROTOV_HIP_GATHER_DELAY_LOCAL", 2);  // C5 forward sweep: 0 -> 26.4, 4 -> 25.8, 6 -> 25.5, 8 -> 26.1 us per step
     a.xmail = h->xmail_d;
     for (int r = 0; r < 8; ++r) a.peer_xmail[r] = h->peer_xmail[r];
 }
