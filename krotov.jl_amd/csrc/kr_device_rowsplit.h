@@ -184,7 +184,8 @@ __device__ __forceinline__ void kr_rs_stream(const __amdgpu_buffer_rsrc_t rsrc, 
                                              const double2 *xp, double (&outr)[1 + LMAX], double (&outi)[1 + LMAX]) {
     using G = KrGeomR<NP, NR, LMAX>;
     constexpr int JS = G::JS, JSR = G::JSR, R = G::R, T = G::THREADS, JQ = G::JQ;
-    constexpr int CH = (MODE == 1 && G::CHUNK > 2 && JS >= 16) ? 2 : G::CHUNK;  // phase A carries 4(1+L) accumulators: smaller chunks
+    constexpr int CH = (MODE == 1 && G::CHUNK > 2 && JS >= 16 && LMAX > 1) ? 2 : G::CHUNK;  // phase A carries 4(1+L) accumulators: smaller chunks
+                                                                                               // (one control, LMAX = 1: room for 4 columns in flight)
     const int tid = threadIdx.x;
     double ar[1 + LMAX], br[1 + LMAX], ai[1 + LMAX], bi[1 + LMAX];
 #pragma unroll
@@ -280,8 +281,9 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     __shared__ __attribute__((aligned(16))) double2 sHl[JSL > 0 ? JSL * G::THREADS : 1];  // LDS part of the H(eps) block
     __shared__ __attribute__((aligned(16))) double2 sx[2][NPP];   // full state vector psi (or chi), by step parity
     __shared__ __attribute__((aligned(16))) double2 sy[2][NPP];   // Horner vectors, ping-pong
-    __shared__ double spart[LMAX * NR];
-    __shared__ double stot[LMAX + 1];
+    constexpr int XL = (LMAX < 2) ? 2 : LMAX;   // slot width of the per-step exchange (kr_exchange: 2 or 4 doubles)
+    __shared__ double spart[XL * NR];
+    __shared__ double stot[XL + 1];
     __shared__ int sflag[2];
 
     // Workgroup -> (trajectory tile, row block).  With a.xcd_group (K % 8 == 0) the R workgroups of a tile have equal
@@ -380,14 +382,14 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
             if (refresh) kr_rs_stream<NP, NR, LMAX, 1>(hrsrc, rb, L, eg, Er, Ei, sHl, &sx[cur][xoff], orr, oi);
             else kr_rs_stream<NP, NR, LMAX, 1, true>(hrsrc, rb, L, dinc, Er, Ei, sHl, &sx[cur][xoff], orr, oi);
             KR_STAMP(tS)
-            double part[LMAX], du[LMAX];
+            double part[XL], du[XL];
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) {
+            for (int l = 0; l < XL; ++l) {
                 part[l] = 0.0;
-                if (l < L && ((gx.present >> l) & 1u)) part[l] = cr * oi[1 + l] - ci * orr[1 + l];
+                if (l < LMAX && l < L && ((gx.present >> l) & 1u)) part[l] = cr * oi[1 + (l < LMAX ? l : 0)] - ci * orr[1 + (l < LMAX ? l : 0)];
             }
             if (n + 1 < NT && row_ok) { const double2 c = a.X[(size_t)(n + 1) * slab + kbase + row]; cr = c.x; ci = c.y; }
-            if (!kr_exchange<LMAX, NR, KR_RS_SCHED>(a, n, wg, owner, il, part, du, spart, stot)) return;
+            if (!kr_exchange<XL, NR, KR_RS_SCHED>(a, n, wg, owner, il, part, du, spart, stot)) return;
             KR_STAMP(tX)
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) {
@@ -478,6 +480,7 @@ static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hi
         else kr_launch_kernel((kr_rowsplit_sweep<NP, NRv, LM, true>), grid, KrGeomR<NP, NRv, LM>::THREADS, 0, s, *a);             \
         return hipGetLastError();                                                                      \
     }
+    KR_CASE_R(1, 8) KR_CASE_R(1, 16) KR_CASE_R(1, 32) KR_CASE_R(1, 64)   // one control: C5's shape
     KR_CASE_R(2, 8) KR_CASE_R(2, 16) KR_CASE_R(2, 32) KR_CASE_R(2, 64)
     KR_CASE_R(4, 8) KR_CASE_R(4, 16) KR_CASE_R(4, 32) KR_CASE_R(4, 64)
 #undef KR_CASE_R

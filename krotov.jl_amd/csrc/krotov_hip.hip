@@ -437,6 +437,8 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
         if ((long long)c.K * R <= maxwg && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
             while (NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
             h->rowsplit = true;
+            if (c.L == 1 && env_int("KROTOV_HIP_RS_LMAX1", 1) != 0) h->LMAXv = 1;   // row-split kernels have an instantiation for ONE control (C5): fewer
+                                                                                 // accumulators and chunk registers in the streaming passes
             h->R = R;
             h->NR = NP / R;
             h->threads = 512;  // mirrors KrGeomR
