@@ -657,3 +657,24 @@ def test_economized_step_polynomial(oracle_c, monkeypatch):
     (_, _, _), info = _iterate(p)
     assert info["economized_polynomial"] == 0
     _run_case(oracle_c, p)
+
+
+def test_rowsplit_one_control_instantiation(oracle_c, monkeypatch):
+    """Row-split kernels (64 < N <= 256) with L = 1 run an instantiation compiled for one control (fewer accumulators, four columns in
+    flight in the streaming passes); it must agree with the two-control kernels (KROTOV_HIP_RS_LMAX1=0) far inside the parity
+    tolerances and with the oracle at them -- Hermitian and non-Hermitian generators, N that does not fill the padded size, K that
+    gives R = 4 and R = 8 workgroups per trajectory."""
+    cases = [wl.dense_problem(100, 40, 6, 1, 191, 0.02, 2.0), wl.dense_problem(256, 36, 24, 1, 192, 0.01, 2.0),
+             wl.dense_problem(130, 35, 40, 1, 193, 0.02, 5.0)]
+    cases[2]["H0"] = cases[2]["H0"] - 0.03j * np.diag(np.random.default_rng(5).uniform(0, 1, 130))
+    for ci, p in enumerate(cases):
+        res = {}
+        for mode in ["0", "1"]:
+            monkeypatch.setenv("KROTOV_HIP_RS_LMAX1", mode)
+            res[mode], info = _iterate(p)
+            assert info["rowsplit_R"] > 0 and info["LMAX"] == (1 if mode == "1" else 2), info
+        assert _rel(res["1"][0], res["0"][0]) < 1e-12, ci
+        assert np.max(np.abs(res["1"][2] - res["0"][2])) < 1e-12 * max(1.0, np.max(np.abs(res["0"][2]))), ci
+    monkeypatch.setenv("KROTOV_HIP_RS_LMAX1", "1")
+    _run_case(oracle_c, cases[0], check_storage=False)
+    _run_case(oracle_c, cases[2], check_storage=False)
