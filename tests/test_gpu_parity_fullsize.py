@@ -11,10 +11,10 @@ inputs, where the short-grid tests of test_gpu_parity.py stop short:
 The oracle runs in shared-propagator mode (one expm per step instead of one per trajectory: the same arithmetic per
 trajectory, K-fold less work) on up to 16 host threads; its update integrand is still summed serially in the reference's
 order (optimize.jl:340-349).  Tolerances (fp64 complex; stated, then what was reached on MI355X in parentheses):
-    updated pulses  1e-10 relative to max|eps|   (C3 full 4.6e-15; C4 shapes 4-7e-16; C5 row-split 1.4e-16; N=100 5.4e-16)
-    final states    1e-9 absolute                (C3 full 5.6e-15; C4 shapes 2.8e-15; C5 6.4e-16; N=100 5.6e-15)
-    int g_a dt      1e-9 relative                (<= 2.1e-14 everywhere)
-    storages        1e-10 absolute, sampled slots (<= 4.6e-15)
+    updated pulses  1e-10 relative to max|eps|   (C3 full 7.0e-15; C4 shapes 8e-16; C5 row-split 1.4e-16; N=100 6.8e-16)
+    final states    1e-9 absolute                (C3 full 2.0e-14; C4 shapes 5.5e-15; C5 6.4e-16; N=100 5.9e-15)
+    int g_a dt      1e-9 relative                (<= 9.7e-14 everywhere)
+    storages        1e-10 absolute, sampled slots (<= 1.5e-14)
 (profiles/r02_parity_fullsize.txt holds the lines the tests print.)
 """
 import os
