@@ -18,7 +18,8 @@
  *
  * Conventions
  *   - every function returns an int status (KR_OK = 0); nothing throws, aborts or longjmps
- *     across the boundary.  kr_last_error() gives the message (the Julia shim turns it into an
+ *     across the boundary: every entry point (and every library-owned thread of a device-list
+ *     handle) runs inside a catch-all that turns C++ exceptions into KR_ERR_INTERNAL + message.  kr_last_error() gives the message (the Julia shim turns it into an
  *     ErrorException, which optimize.jl:218-226 already captures).
  *   - operators: N*N complex128, COLUMN-major, interleaved (re,im) = Julia Matrix{ComplexF64}.
  *   - states: [K][N] complex128 interleaved, trajectory-major (one Vector{ComplexF64} after the
@@ -52,7 +53,9 @@ enum kr_status {
     KR_ERR_HIP = 3,         /* a HIP runtime call failed                                       */
     KR_ERR_UNSUPPORTED = 4, /* valid request outside what this build implements                */
     KR_ERR_TIMEOUT = 5,     /* an in-kernel bounded spin gave up (device status word set)      */
-    KR_ERR_STATE = 6        /* call order violated (e.g. update before backward)               */
+    KR_ERR_STATE = 6,       /* call order violated (e.g. update before backward)               */
+    KR_ERR_INTERNAL = 7     /* a C++ exception (std::bad_alloc, std::system_error, ...) was caught at the
+                               boundary; the message names it.  Nothing propagates into the caller.     */
 };
 
 enum kr_flags {
@@ -118,7 +121,13 @@ typedef struct kr_config {
     int32_t control_poly_degree;   /* 0 (linear) or 1..7                                         */
     int32_t pad_;
     const double *control_poly;    /* [L][control_poly_degree + 1], or NULL                      */
-    int32_t reserved[8];
+    /* Bound of every in-kernel spin (per-step exchange between workgroups / GPUs, row-split all-gather, cross-rank tau sum)
+     * in milliseconds; 0 = the default 4000.  With one process per GPU the ranks run unsynchronised between iterations, so
+     * a rank whose host-side chi / callback takes longer than this bound makes the OTHER ranks' sweeps give up with
+     * KR_ERR_TIMEOUT: size it to the slowest host step.  (Occupies the first of the formerly reserved words: a v2 caller
+     * that zeroed `reserved` gets the default.)                                                                          */
+    int32_t spin_timeout_ms;
+    int32_t reserved[7];
 } kr_config;
 
 typedef struct kr_handle kr_handle;
@@ -175,6 +184,10 @@ int kr_read_storage(kr_handle *h, int which, int k, int n, double *out /* [N] */
  * events on the handle's stream; kr_get_timings syncs the stream and returns, per kind
  * {forward, backward, update}: {sum of kernel durations in ms, number of launches} (6 doubles). */
 int kr_get_info(kr_handle *h, int32_t *info_out /* [16] */);
+/* One human-readable line: which kernels carry this handle's sweeps, grid, exchange, spin bound -- and, when the problem left the
+ * persistent kernels (capacity, co-residency, RCCL / callback exchange) or something could not be verified (occupancy query),
+ * why.  Valid until kr_destroy; "" for NULL.                                                                              */
+const char *kr_plan_description(const kr_handle *h);
 int kr_get_timings(kr_handle *h, double *timings_ms /* [6] */);
 int kr_enable_timing(kr_handle *h, int on);
 /* Diagnostics (env KROTOV_HIP_STAMPS=1 at kr_create): workgroup 0's accumulated shader cycles of the last

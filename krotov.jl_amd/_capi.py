@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KROTOV_HIP_LIB", os.path.join(_HERE, "lib", "libkrotov_hip.so"))  # env: A/B builds
 
 KR_ABI_VERSION = 2
-KR_OK, KR_ERR_INVALID, KR_ERR_NO_DEVICE, KR_ERR_HIP, KR_ERR_UNSUPPORTED, KR_ERR_TIMEOUT, KR_ERR_STATE = range(7)
+KR_OK, KR_ERR_INVALID, KR_ERR_NO_DEVICE, KR_ERR_HIP, KR_ERR_UNSUPPORTED, KR_ERR_TIMEOUT, KR_ERR_STATE, KR_ERR_INTERNAL = range(8)
 KR_STORE_FW, KR_NO_STORE_FW = 1, 2
 KR_J_T_SM, KR_J_T_SS, KR_J_T_RE = 0, 1, 2
 KR_STORAGE_FW, KR_STORAGE_BW = 0, 1
@@ -23,7 +23,7 @@ EXPORTS = [
     "kr_set_initial_states", "kr_set_target_states", "kr_forward", "kr_backward",
     "kr_update_forward", "kr_iteration", "kr_set_update_params", "kr_forward_dev",
     "kr_iteration_functional_dev", "kr_final_states", "kr_taus", "kr_g_a_int", "kr_synchronize",
-    "kr_read_storage", "kr_get_info", "kr_get_timings", "kr_enable_timing", "kr_debug_stamps", "kr_debug_arrivals",
+    "kr_read_storage", "kr_get_info", "kr_plan_description", "kr_get_timings", "kr_enable_timing", "kr_debug_stamps", "kr_debug_arrivals",
     "kr_ipc_handle_size", "kr_ipc_export", "kr_ipc_connect",
     "kr_rccl_unique_id_size", "kr_rccl_get_unique_id", "kr_rccl_init", "kr_set_exchange_callback",
 ]
@@ -43,7 +43,7 @@ class KrConfig(C.Structure):
         ("exchange", C.c_int32), ("prop_method", C.c_int32), ("max_workgroups", C.c_int32),
         ("n_devices", C.c_int32), ("devices", C.c_int32 * 8),
         ("control_poly_degree", C.c_int32), ("pad_", C.c_int32), ("control_poly", C.c_void_p),
-        ("reserved", C.c_int32 * 8),
+        ("spin_timeout_ms", C.c_int32), ("reserved", C.c_int32 * 7),
     ]
 
 
@@ -97,9 +97,11 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.kr_last_error.restype = C.c_char_p
     lib.kr_last_error.argtypes = [C.c_void_p]
+    lib.kr_plan_description.restype = C.c_char_p
+    lib.kr_plan_description.argtypes = [C.c_void_p]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name != "kr_last_error":
+        if name not in ("kr_last_error", "kr_plan_description"):
             fn.restype = C.c_int
     lib.kr_create.argtypes = [C.POINTER(KrConfig), C.POINTER(C.c_void_p)]
     _lib = lib

@@ -13,7 +13,8 @@
 #ifndef KR_APPLY_JQ64
 #define KR_APPLY_JQ64 8          // lanes per row of the apply sweep at NP = 64 (8: 512-thread workgroups)
 #endif
-#define KR_SPIN_TIMEOUT_TICKS 400000000ull  // 4 s of s_memrealtime (100 MHz): bounded spin
+#define KR_SPIN_DEFAULT_TICKS 400000000ull  // 4 s of s_memrealtime (100 MHz): default bound of every in-kernel spin
+                                            // (kr_config.spin_timeout_ms overrides it per handle: KrSweepArgs::spin_ticks)
 
 // status words (device): [0] abort/timeout flag, [1] where, [2] step, [3] spare
 #define KR_STATUS_WORDS 4
@@ -63,6 +64,7 @@ struct KrSweepArgs {
     int P;                   // workgroups
     int rank, world;
     unsigned epoch_base;     // tags = epoch_base + n + 1
+    unsigned long long spin_ticks; // bound of every in-kernel spin in s_memrealtime ticks (100 MHz); kr_config.spin_timeout_ms
     int use_mfma;            // propagator build on the matrix cores where available (NP = 64)
 };
 
@@ -143,6 +145,10 @@ static inline void kr_launch_kernel(Kern k, int grid, int threads, size_t lds, h
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, a);
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the code object loaded on ONE device: raise it once per (kernel, device
+// that is current), under a lock -- a handle with a device list launches from several threads on several GPUs (krotov_hip.hip).
+hipError_t kr_raise_dynamic_lds(const void *func, int bytes);
 
 typedef hipError_t (*kr_launch_fn)(int variant_lmax, int variant_kt, int kind, int grid,
                                    hipStream_t stream, const KrSweepArgs *args);

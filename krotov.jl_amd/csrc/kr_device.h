@@ -530,7 +530,7 @@ __device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int 
         if (__all(kr_poll_pass<LMAX>(a, par, phase, lane, tot))) break;
         if ((spins & 63u) == 0u) {
             const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (st != 0u || kr_realtime() - t0 > KR_SPIN_TIMEOUT_TICKS) return false;
+            if (st != 0u || kr_realtime() - t0 > a.spin_ticks) return false;
         }
     }
 #pragma unroll
@@ -666,7 +666,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 if (__all(ok)) break;
                 if ((++spins & 63u) == 0u) {
                     const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (st != 0u || kr_realtime() - t0 > KR_SPIN_TIMEOUT_TICKS) {
+                    if (st != 0u || kr_realtime() - t0 > a.spin_ticks) {
                         if (lane == 0 && st == 0u) {
                             __hip_atomic_store((kr_gu32 *)a.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store((kr_gu32 *)a.status + 2, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -718,7 +718,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                     if (__all(ok)) break;
                     if ((++spins & 63u) == 0u) {
                         const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (st != 0u || kr_realtime() - t1 > KR_SPIN_TIMEOUT_TICKS) {
+                        if (st != 0u || kr_realtime() - t1 > a.spin_ticks) {
                             if (lane == 0 && st == 0u) {
                                 __hip_atomic_store((kr_gu32 *)a.status + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 __hip_atomic_store((kr_gu32 *)a.status + 2, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1111,8 +1111,8 @@ static void kr_launch_expm(int grid, hipStream_t s, const KrSweepArgs *a) {
     if constexpr (NP == 64) {
         if (a->use_mfma) {
             constexpr size_t lds = (size_t)4 * 64 * KR_YS * sizeof(double);
-            static const bool ok = hipFuncSetAttribute((const void *)kr_expm_mfma64<LM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-            if (ok) {
+            // (per kernel AND device: kr_raise_dynamic_lds; on failure the VALU build kernel below carries the sweep)
+            if (kr_raise_dynamic_lds((const void *)kr_expm_mfma64<LM>, (int)lds) == hipSuccess) {
                 kr_launch_kernel((kr_expm_mfma64<LM>), grid, 256, lds, s, *a);
                 return;
             }

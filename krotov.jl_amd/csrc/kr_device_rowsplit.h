@@ -135,7 +135,7 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
             if (__all(ok)) break;
             if ((++spins & 63u) == 0u) {
                 const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (st != 0u || kr_realtime() - t0 > KR_SPIN_TIMEOUT_TICKS) {
+                if (st != 0u || kr_realtime() - t0 > a.spin_ticks) {
                     if (lane == 0 && st == 0u) {
                         __hip_atomic_store((kr_gu32 *)a.status + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store((kr_gu32 *)a.status + 2, box.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -325,7 +325,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
                 const unsigned long long v = __hip_atomic_load((kr_gu64 *)xtab + tile * R + (lane % R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool got = ((unsigned)(v >> 32) == ltag);
                 if (__all(got)) { same = __all((unsigned)(v & 15u) == (xcc & 15u)); break; }
-                if (kr_realtime() - t0 > KR_SPIN_TIMEOUT_TICKS / 64) break;  // never arrived: stay on the placement-independent path
+                if (kr_realtime() - t0 > a.spin_ticks / 64) break;  // never arrived: stay on the placement-independent path
             }
             if (lane == 0) sflag[0] = same ? 1 : 0;
         }

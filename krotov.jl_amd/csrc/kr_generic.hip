@@ -5,14 +5,12 @@
 hipError_t kr_launch_generic(int kind, int ktg, int grid, size_t lds_bytes, hipStream_t s, const KrGenArgs *a) {
 #define KR_GEN_KTG(KTG)                                                                                                 \
     if (ktg == KTG) {                                                                                                   \
-        if (lds_bytes > 48 * 1024) {                                                                                    \
-            static bool raised = false;                                                                                 \
-            if (!raised) {                                                                                              \
-                (void)hipFuncSetAttribute((const void *)kr_gen_known<KTG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-                (void)hipFuncSetAttribute((const void *)kr_gen_partial<KTG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); \
-                (void)hipFuncSetAttribute((const void *)kr_gen_apply<KTG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-                raised = true;                                                                                          \
-            }                                                                                                           \
+        if (lds_bytes > 48 * 1024) {   /* per (kernel, device): a device-list handle launches on several GPUs (kr_raise_dynamic_lds) */ \
+            hipError_t e_ = hipSuccess;                                                                                 \
+            if (kind == 0) e_ = kr_raise_dynamic_lds((const void *)kr_gen_known<KTG>, 160 * 1024);                     \
+            else if (kind == 1) e_ = kr_raise_dynamic_lds((const void *)kr_gen_partial<KTG>, 160 * 1024 - 2048);       \
+            else if (kind == 4) e_ = kr_raise_dynamic_lds((const void *)kr_gen_apply<KTG>, 160 * 1024);                \
+            if (e_ != hipSuccess) return e_;                                                                            \
         }                                                                                                               \
         if (kind == 0) hipLaunchKernelGGL((kr_gen_known<KTG>), dim3(grid), dim3(256), lds_bytes, s, *a);                \
         else if (kind == 1) hipLaunchKernelGGL((kr_gen_partial<KTG>), dim3(grid), dim3(256), lds_bytes, s, *a);         \

@@ -20,9 +20,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <string>
+#include <tuple>
 #include <vector>
 
 typedef std::complex<double> zc;
@@ -86,6 +89,10 @@ struct kr_handle {
     unsigned *status_d = nullptr;
     unsigned long long *debug_d = nullptr;
     bool debug_on = false;
+    unsigned long long spin_ticks = KR_SPIN_DEFAULT_TICKS;   // kr_config.spin_timeout_ms
+    std::string plan_note;     // why a problem left the persistent kernels / what could not be verified
+    std::string plan_text;     // kr_plan_description(): one line, written at the end of kr_create
+    int sets = 1;              // tile sets a persistent workgroup time-multiplexes within a step (K beyond one set per CU)
     unsigned epoch_base = 0;
     unsigned func_epoch = 0;   // tag of the cross-rank tau sums (J_T_sm on the device, world > 1)
     bool have_psi0 = false, have_tgt = false, have_X = false, have_final = false, have_params = false;
@@ -128,6 +135,34 @@ static int fail(kr_handle *h, int code, const char *fmt, ...) {
     va_end(ap);
     if (h) h->err = buf; else g_create_error = buf;
     return code;
+}
+
+// ---- nothing throws across the C boundary --------------------------------------------------------
+// Every extern "C" entry point and every library-owned thread runs its body through kr_guard: std::bad_alloc from the staging
+// vectors / new kr_handle, std::system_error from std::thread, anything else -> KR_ERR_INTERNAL + message, never an exception
+// (or std::terminate) inside a ccall (/root/reference/src/optimize.jl:218-226 only knows Julia exceptions).
+static int fail_nothrow(kr_handle *h, int code, const char *where, const char *what) noexcept {
+    try { return fail(h, code, "%s: C++ exception caught at the library boundary: %s", where, what); } catch (...) { return code; }
+}
+template <class F>
+static int kr_guard(kr_handle *h, const char *where, F &&f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc &) { return fail_nothrow(h, KR_ERR_INTERNAL, where, "out of host memory (std::bad_alloc)"); }
+    catch (const std::exception &e) { return fail_nothrow(h, KR_ERR_INTERNAL, where, e.what()); }
+    catch (...) { return fail_nothrow(h, KR_ERR_INTERNAL, where, "unknown exception"); }
+}
+
+hipError_t kr_raise_dynamic_lds(const void *func, int bytes) {
+    static std::mutex mtx;
+    static std::vector<std::tuple<const void *, int, int>> done;   // (kernel, device, bytes)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mtx);
+    for (auto &d : done) if (std::get<0>(d) == func && std::get<1>(d) == dev && std::get<2>(d) >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.emplace_back(func, dev, bytes);
+    return e;
 }
 
 #define HIPCHK(h, call)                                                                     \
@@ -315,7 +350,7 @@ __global__ __launch_bounds__(256) void kr_tausum_kernel(const double2 *tau, doub
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-__global__ void kr_taugather_kernel(unsigned long long *xmail, double2 *out, int world, unsigned tag, unsigned *status) {
+__global__ void kr_taugather_kernel(unsigned long long *xmail, double2 *out, int world, unsigned tag, unsigned *status, unsigned long long spin_ticks) {
     const int lane = threadIdx.x, par = (int)(tag & 1u);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     double re = 0, im = 0;
@@ -329,7 +364,7 @@ __global__ void kr_taugather_kernel(unsigned long long *xmail, double2 *out, int
             im = __longlong_as_double((long long)((g[3] << 32) | (g[2] & 0xffffffffull)));
         }
         if (__all(ok)) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > KR_SPIN_TIMEOUT_TICKS) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
             if (lane == 0) { status[1] = 4u; status[2] = tag; __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             break;
         }
@@ -528,11 +563,38 @@ static int gen_geometry(kr_handle *h, int ktile_limit) {
     return KR_OK;
 }
 
+// HERM variant of the update kernel: every control operator that enters the update integrand is exactly Hermitian
+// (KROTOV_HIP_HERM: 0 = never, 1 = where it was measured to pay: one trajectory per team and >= 64 workgroups -- C3
+// 6.63 -> 5.91 us per step, N = 32 / 16 / 8 at P = 256: 5.44 -> 5.07, 4.59 -> 4.38, 4.38 -> 4.26; KT = 2: 9.9 -> 10.1, KT = 4
+// at N = 64: 17.6 -> 29 (scratch), P = 8: 4.30 -> 4.45 --, 2 = whenever the operators allow it).  Decided inside make_plan:
+// the co-residency query must ask about the variant that will really be launched.
+static void decide_herm(kr_handle *h, const kr_config *cfg) {
+    const int N = cfg->N, L = cfg->L, G = cfg->G;
+    const size_t nn = (size_t)N * N;
+    const zc *Hc = (const zc *)cfg->Hc;
+    const int mode = env_int("KROTOV_HIP_HERM", 1);
+    // (matrix-core sweep: with one tile per workgroup the window hides phase A -- K = 512: 8.0k against ~8.9k cycles for
+    //  dot + exchange --, with two tiles its five products outlast the exchange: C4 11.74 vs 11.35 us per step)
+    h->herm = (mode == 2) || (mode == 1 && (h->mfma_sweep ? h->KT == 2 : h->KT == 1) && h->P >= 64 && h->NP <= 64);
+    if (h->mfma_sweep && h->LMAXv == 4 && h->KT == 4) h->herm = false;   // that instantiation spills (212 B): general variant
+    if (h->rowsplit || h->NP > 64) h->herm = false;
+    for (int g = 0; g < G && h->herm; ++g) {
+        for (int l = 0; l < L && h->herm; ++l) {
+            if (cfg->hc_present && !cfg->hc_present[(size_t)g * L + l]) continue;
+            const zc *M = Hc + ((size_t)g * L + l) * nn;
+            for (int c = 0; c < N && h->herm; ++c)
+                for (int r = 0; r <= c; ++r)
+                    if (M[(size_t)c * N + r] != std::conj(M[(size_t)r * N + c])) { h->herm = false; break; }
+        }
+    }
+}
+
 // Plan: the persistent kernels where they have one; the generic kernels for what they cannot carry (N > 256, L > 4, more
 // trajectories than co-resident workgroups) and for the update sweep whenever the per-step exchange runs outside the kernel
 // (RCCL / callback).  KROTOV_HIP_GENERIC = 1 forces the generic kernels everywhere (tests), 0 forbids the fallback.
-static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) {
+static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_gen) {
     const kr_config &c = h->cfg;
+    const int32_t *tg = full->traj_generator;
     const int genv = env_int("KROTOV_HIP_GENERIC", -1);
     if (c.L > 32) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > 32 controls not supported", c.L);
     if (c.exchange < KR_EXCHANGE_AUTO || c.exchange > KR_EXCHANGE_CALLBACK) return fail(h, KR_ERR_INVALID, "kr_create: exchange = %d", c.exchange);
@@ -552,18 +614,31 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
         // runtime cannot know -- other processes on the same GPU -- is the caller's to declare: kr_config.max_workgroups.)
         hipDeviceProp_t prop;
         HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+        decide_herm(h, full);
         KrOccQuery &q = kr_occ_query();
         KrSweepArgs dummy;
         memset(&dummy, 0, sizeof dummy);
-        q.on = 1; q.blocks_per_cu = -2;
-        if (h->rowsplit) (void)h->launch_rs(h->LMAXv, h->NR, 1, h->P, nullptr, &dummy);
-        else if (h->mfma_sweep) (void)kr_launch_mf64(h->LMAXv, h->KT / 2, 1, h->P, nullptr, &dummy);
-        else (void)h->launch(h->LMAXv, h->KT, 1, h->P, nullptr, &dummy);
-        q.on = 0;
-        const long long room = (long long)std::max(q.blocks_per_cu, 0) * prop.multiProcessorCount;
-        if (q.blocks_per_cu != -2 && room < h->P) {
+        // the variants launch_update may really pick: this handle's HERM, either exchange schedule (calibrate_exchange decides)
+        int worst = 1 << 30;
+        bool unknown = false;
+        for (int sched = 0; sched < 2; ++sched) {
+            int kind = 1;
+            if (h->NP <= 64 && !h->rowsplit) kind |= (sched ? 16 : 0) | (h->herm ? 64 : 0);
+            else if (sched) break;
+            q.on = 1; q.blocks_per_cu = -2;
+            if (h->rowsplit) (void)h->launch_rs(h->LMAXv, h->NR, 1, h->P, nullptr, &dummy);
+            else if (h->mfma_sweep) (void)kr_launch_mf64(h->LMAXv, h->KT / 2, kind, h->P, nullptr, &dummy);
+            else (void)h->launch(h->LMAXv, h->KT, kind, h->P, nullptr, &dummy);
+            q.on = 0;
+            if (q.blocks_per_cu < 0) unknown = true;   // -2: this launcher has no query mode; -1: the runtime's query failed
+            else worst = std::min(worst, q.blocks_per_cu);
+        }
+        // a failed query is "unknown", not "zero": keep the persistent plan (its spins are bounded) and say so
+        if (unknown) h->plan_note = "occupancy query unavailable for the update kernel: co-residency of the persistent grid not verified";
+        const long long room = (long long)(worst == (1 << 30) ? (1 << 20) : worst) * prop.multiProcessorCount;
+        if (room < h->P) {
             fail(h, KR_ERR_UNSUPPORTED, "the update sweep needs %d co-resident workgroups but this device holds %lld of them (%d per CU x %d CUs)",
-                 h->P, room, q.blocks_per_cu, prop.multiProcessorCount);
+                 h->P, room, worst, prop.multiProcessorCount);
             h->fast_ok = false;
             rc = KR_ERR_UNSUPPORTED;
         }
@@ -586,6 +661,7 @@ static int make_plan(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen) 
         return KR_OK;
     }
     // everything generic: own layout (generator groups one after the other, each padded to whole tiles of KTG)
+    h->plan_note = "generic multi-pass kernels" + (h->err.empty() ? std::string() : " (" + h->err + ")");
     h->err.clear();
     h->mfma_sweep = false; h->rowsplit = false; h->herm = false;
     rc = gen_geometry(h, 0);
@@ -669,9 +745,10 @@ static hipError_t alloc_mailbox(kr_handle *h, unsigned long long **p, size_t wor
 static int calibrate_exchange(kr_handle *h);  // defined below, next to launch_update
 static int check_status(kr_handle *h);
 
-static int one_create(const kr_config *cfg, kr_handle **out) {
+static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&live) {
     if (out) *out = nullptr;
     if (!cfg || !out) return fail(nullptr, KR_ERR_INVALID, "kr_create: null argument");
+    if (cfg->spin_timeout_ms < 0) return fail(nullptr, KR_ERR_INVALID, "kr_create: spin_timeout_ms = %d must be >= 0 (0 = default 4000)", cfg->spin_timeout_ms);
     if (cfg->abi_version != KR_ABI_VERSION) return fail(nullptr, KR_ERR_INVALID, "kr_create: abi_version %d != %d", cfg->abi_version, KR_ABI_VERSION);
     if (cfg->L <= 0) return fail(nullptr, KR_ERR_INVALID, "no controls in trajectories: cannot optimize");  // workspace.jl:72
     if (cfg->N <= 0 || cfg->NT <= 0 || cfg->K <= 0) return fail(nullptr, KR_ERR_INVALID, "kr_create: N, NT, K must be positive (got %d, %d, %d)", cfg->N, cfg->NT, cfg->K);
@@ -690,10 +767,14 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
     if (e != hipSuccess || ndev <= 0)
         return fail(nullptr, KR_ERR_NO_DEVICE, "no HIP device available (%s); libkrotov_hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
     int dev = cfg->device;
-    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
-    if (dev >= ndev) return fail(nullptr, KR_ERR_INVALID, "kr_create: device %d out of range (%d devices)", dev, ndev);
+    // a device list of ONE entry names the device (kr_create only takes the group path for n_devices > 1)
+    if (cfg->n_devices == 1) dev = cfg->devices[0];
+    else if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev < 0 || dev >= ndev) return fail(nullptr, KR_ERR_INVALID, "kr_create: device %d out of range (%d devices)", dev, ndev);
 
     kr_handle *h = new kr_handle();
+    live = h;
+    if (cfg->spin_timeout_ms > 0) h->spin_ticks = (unsigned long long)cfg->spin_timeout_ms * 100000ull;   // s_memrealtime: 100 MHz
     h->cfg = *cfg;
     h->cfg.traj_generator = nullptr; h->cfg.tlist = nullptr; h->cfg.H0 = nullptr; h->cfg.Hc = nullptr; h->cfg.hc_present = nullptr;
     if (h->cfg.K_global <= 0) h->cfg.K_global = cfg->K;
@@ -717,7 +798,7 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
         h->thr[0] = 0.0;
     }
     int rc = KR_OK;
-    auto bail = [&](int code) { g_create_error = h->err; (void)hipSetDevice(dev); free_all(h); delete h; return code; };
+    auto bail = [&](int code) { g_create_error = h->err; (void)hipSetDevice(dev); free_all(h); live = nullptr; delete h; return code; };
 #define CHK(call) do { hipError_t e2_ = (call); if (e2_ != hipSuccess) { fail(h, KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2_)); return bail(KR_ERR_HIP); } } while (0)
     CHK(hipSetDevice(dev));
     h->G = cfg->G;
@@ -732,7 +813,7 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
         CHK(hipMemcpy(h->poly_d, cfg->control_poly, (size_t)cfg->L * (h->poly_deg + 1) * sizeof(double), hipMemcpyHostToDevice));
     }
     std::vector<int> wg_gen;
-    rc = make_plan(h, cfg->traj_generator, wg_gen);
+    rc = make_plan(h, cfg, wg_gen);
     if (rc != KR_OK) return bail(rc);
     CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
@@ -758,26 +839,6 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
             nrm_gen[(size_t)g * (1 + L) + 1 + l] = norm2_bound(N, Hc + ((size_t)g * L + l) * nn);
         }
         for (int m = 0; m <= L && m <= KR_LMAX_CAP; ++m) nrm[(size_t)g * (1 + KR_LMAX_CAP) + m] = nrm_gen[(size_t)g * (1 + L) + m];
-    }
-    // HERM variant of the update kernel: every control operator that enters the update integrand is exactly Hermitian
-    // (KROTOV_HIP_HERM: 0 = never, 1 = where it was measured to pay: one trajectory per team and >= 64 workgroups -- C3
-    // 6.63 -> 5.91 us per step, N = 32 / 16 / 8 at P = 256: 5.44 -> 5.07, 4.59 -> 4.38, 4.38 -> 4.26; KT = 2: 9.9 -> 10.1, KT = 4
-    // at N = 64: 17.6 -> 29 (scratch), P = 8: 4.30 -> 4.45 --, 2 = whenever the operators allow it)
-    {
-        const int mode = env_int("KROTOV_HIP_HERM", 1);
-        // (matrix-core sweep: with one tile per workgroup the window hides phase A -- K = 512: 8.0k against ~8.9k cycles for
-        //  dot + exchange --, with two tiles its five products outlast the exchange: C4 11.74 vs 11.35 us per step)
-        h->herm = (mode == 2) || (mode == 1 && (h->mfma_sweep ? h->KT == 2 : h->KT == 1) && h->P >= 64 && h->NP <= 64);
-        if (h->mfma_sweep && h->LMAXv == 4 && h->KT == 4) h->herm = false;   // that instantiation spills (212 B): general variant
-    }
-    for (int g = 0; g < G && h->herm; ++g) {
-        for (int l = 0; l < L && h->herm; ++l) {
-            if (!((present[g] >> l) & 1u)) continue;
-            const zc *M = Hc + ((size_t)g * L + l) * nn;
-            for (int c = 0; c < N && h->herm; ++c)
-                for (int r = 0; r <= c; ++r)
-                    if (M[(size_t)c * N + r] != std::conj(M[(size_t)r * N + c])) { h->herm = false; break; }
-        }
     }
     // Economized step polynomial (KrEcon, kr_device.h): needs a real spectrum, i.e. EVERY operator of every generator exactly
     // Hermitian; register-resident update kernels only (N <= 64).  KROTOV_HIP_ECON = 0 switches it off.
@@ -954,8 +1015,35 @@ static int one_create(const kr_config *cfg, kr_handle **out) {
 #undef CHK
     rc = calibrate_exchange(h);
     if (rc != KR_OK) return bail(rc);
+    {   // kr_plan_description(): which kernels carry this problem, and why if not the persistent ones
+        char buf[640];
+        const char *upd = h->gen_update ? "generic per-step kernels (kr_gen_partial/reduce/form/apply)"
+                        : h->rowsplit ? "kr_rowsplit_sweep" : h->mfma_sweep ? "kr_mf_update (matrix cores)"
+                        : h->NP > 64 ? "kr_stream_update" : "kr_sweep_update";
+        const char *known = h->gen_known ? "kr_gen_known" : h->rowsplit ? "kr_rowsplit_sweep" : h->precomp ? "kr_expm + kr_sweep_apply" : "kr_sweep_known";
+        static const char *const exn[] = {"auto", "mailbox", "rccl", "callback"};
+        snprintf(buf, sizeof buf, "N=%d (padded %d) NT=%d K=%d (padded %d) L=%d G=%d rank %d/%d on device %d: update sweep = %s, %d workgroups x %d "
+                 "trajectories, sets per workgroup %d, R=%d, HERM=%d, economized=%d, poll_delay=%d; known-pulse sweeps = %s; exchange = %s; spin bound %.0f ms%s%s",
+                 h->cfg.N, h->NP, h->cfg.NT, h->cfg.K, h->Kp, h->cfg.L, h->G, h->cfg.rank, h->cfg.world, h->device, upd, h->P, h->KTILE, h->sets,
+                 h->rowsplit ? h->R : 1, h->herm ? 1 : 0, h->econ ? 1 : 0, h->poll_delay, known, exn[h->exchange & 3], (double)h->spin_ticks / 1e5,
+                 h->plan_note.empty() ? "" : "; note: ", h->plan_note.c_str());
+        h->plan_text = buf;
+    }
+    live = nullptr;
     *out = h;
     return KR_OK;
+}
+// An exception in the middle of kr_create (std::bad_alloc in a staging vector, ...) must not leak the half-built handle and
+// its device memory: free what exists, then let kr_guard turn the exception into a status.
+static int one_create(const kr_config *cfg, kr_handle **out) {
+    kr_handle *live = nullptr;
+    try {
+        return one_create_impl(cfg, out, live);
+    } catch (...) {
+        if (live) { (void)hipSetDevice(live->device); free_all(live); delete live; }
+        if (out) *out = nullptr;
+        throw;
+    }
 }
 
 static int one_set_stream(kr_handle *h, void *hip_stream) {
@@ -1076,6 +1164,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.N = h->cfg.N; a.NT = h->cfg.NT; a.Kp = h->Kp; a.L = h->cfg.L;
     a.P = h->P; a.rank = h->cfg.rank; a.world = h->cfg.world;
     a.tol = h->tol;
+    a.spin_ticks = h->spin_ticks;
     memcpy(a.thr, h->thr, sizeof a.thr);
     a.use_mfma = h->use_mfma ? 1 : 0;
     a.gmail = h->gmail_d;
@@ -1650,8 +1739,16 @@ static int one_iteration_functional_dev(kr_handle *h, int functional, const void
     if (!h->have_psi0 || !h->have_tgt) return fail(h, KR_ERR_STATE, "device chain: initial and target states must be set");
     if (!h->have_final) return fail(h, KR_ERR_STATE, "device chain: no forward sweep has produced final states yet");
     if (!h->have_params) return fail(h, KR_ERR_STATE, "device chain: kr_set_update_params has not been called");
-    if (functional == KR_J_T_SM && h->cfg.world > 1 && !h->peers_connected)
-        return fail(h, KR_ERR_STATE, "J_T_sm couples trajectories across ranks: the sum of the taus travels through the peer mailboxes (kr_ipc_connect, or a device list)");
+    // J_T_sm couples ALL trajectories: the sum of the taus crosses the ranks through the handle's own carrier -- the tau slots of
+    // the peer mailboxes, one ncclAllReduce of 2 doubles, or the host callback
+    const bool tau_rccl = h->cfg.world > 1 && h->gen_update && h->exchange == KR_EXCHANGE_RCCL;
+    const bool tau_cb = h->cfg.world > 1 && h->gen_update && h->exchange == KR_EXCHANGE_CALLBACK;
+    if (functional == KR_J_T_SM && h->cfg.world > 1) {
+        if (tau_rccl && !h->rccl_comm) return fail(h, KR_ERR_STATE, "J_T_sm across ranks with exchange = RCCL: kr_rccl_init has not been called");
+        if (tau_cb && !h->cb) return fail(h, KR_ERR_STATE, "J_T_sm across ranks with exchange = CALLBACK: kr_set_exchange_callback has not been called");
+        if (!tau_rccl && !tau_cb && !h->peers_connected)
+            return fail(h, KR_ERR_STATE, "J_T_sm couples trajectories across ranks: the sum of the taus travels through the peer mailboxes (kr_ipc_connect, or a device list)");
+    }
     HIPCHK(h, hipSetDevice(h->device));
     const int K = h->Kp, N = h->cfg.N;
     int rc = launch_tau(h);
@@ -1660,10 +1757,22 @@ static int one_iteration_functional_dev(kr_handle *h, int functional, const void
         KrPeers peers;
         for (int r = 0; r < 8; ++r) peers.p[r] = h->peer_xmail[r];
         const unsigned tag = ++h->func_epoch;
-        hipLaunchKernelGGL(kr_tausum_kernel, dim3(1), dim3(256), 0, h->stream, h->tau_d, h->tausum_d, K, h->cfg.world, h->cfg.rank, tag, peers);
+        const bool via_mail = h->cfg.world > 1 && !tau_rccl && !tau_cb;
+        hipLaunchKernelGGL(kr_tausum_kernel, dim3(1), dim3(256), 0, h->stream, h->tau_d, h->tausum_d, K, via_mail ? h->cfg.world : 1, h->cfg.rank, tag, peers);
         HIPCHK(h, hipGetLastError());
-        if (h->cfg.world > 1) {
-            hipLaunchKernelGGL(kr_taugather_kernel, dim3(1), dim3(64), 0, h->stream, h->xmail_d, h->tausum_d, h->cfg.world, tag, h->status_d);
+        if (tau_rccl) {   // (sum order = RCCL's: identical on every rank, as the update sweep's all-reduce is)
+            const ncclResult_t r = kr_rccl()->AllReduce(h->tausum_d, h->tausum_d, 2, ncclDouble, ncclSum, h->rccl_comm, h->stream);
+            if (r != ncclSuccess) return fail(h, KR_ERR_HIP, "ncclAllReduce of the tau sum failed: %s", kr_rccl()->GetErrorString(r));
+        } else if (tau_cb) {
+            double buf[2];
+            HIPCHK(h, hipMemcpyAsync(buf, h->tausum_d, sizeof buf, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const int crc = h->cb(h->cb_ctx, buf, 2);
+            if (crc != 0) return fail(h, KR_ERR_HIP, "exchange callback returned %d for the tau sum", crc);
+            HIPCHK(h, hipMemcpyAsync(h->tausum_d, buf, sizeof buf, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));   // (buf is a local)
+        } else if (h->cfg.world > 1) {
+            hipLaunchKernelGGL(kr_taugather_kernel, dim3(1), dim3(64), 0, h->stream, h->xmail_d, h->tausum_d, h->cfg.world, tag, h->status_d, h->spin_ticks);
             HIPCHK(h, hipGetLastError());
         }
     }
@@ -1739,14 +1848,16 @@ static int one_read_storage(kr_handle *h, int which, int k, int n, double *out) 
 extern "C" int kr_rccl_unique_id_size(void) { return (int)sizeof(ncclUniqueId); }
 
 extern "C" int kr_rccl_get_unique_id(void *id_out) {
-    if (!id_out) return fail(nullptr, KR_ERR_INVALID, "kr_rccl_get_unique_id: null");
-    KrRccl *r = kr_rccl();
-    if (!r) return fail(nullptr, KR_ERR_UNSUPPORTED, "%s", kr_rccl_why());
-    ncclUniqueId id;
-    const ncclResult_t rc = r->GetUniqueId(&id);
-    if (rc != ncclSuccess) return fail(nullptr, KR_ERR_HIP, "ncclGetUniqueId failed: %s", r->GetErrorString(rc));
-    memcpy(id_out, &id, sizeof id);
-    return KR_OK;
+    return kr_guard(nullptr, "kr_rccl_get_unique_id", [&]() -> int {
+        if (!id_out) return fail(nullptr, KR_ERR_INVALID, "kr_rccl_get_unique_id: null");
+        KrRccl *r = kr_rccl();
+        if (!r) return fail(nullptr, KR_ERR_UNSUPPORTED, "%s", kr_rccl_why());
+        ncclUniqueId id;
+        const ncclResult_t rc = r->GetUniqueId(&id);
+        if (rc != ncclSuccess) return fail(nullptr, KR_ERR_HIP, "ncclGetUniqueId failed: %s", r->GetErrorString(rc));
+        memcpy(id_out, &id, sizeof id);
+        return KR_OK;
+    });
 }
 
 static int one_rccl_init(kr_handle *h, const void *unique_id) {
@@ -1814,8 +1925,15 @@ static int group_run(kr_handle *g, F f) {
     const int P = (int)g->subs.size();
     std::vector<int> rcs(P, KR_OK);
     std::vector<std::thread> th;
-    for (int i = 1; i < P; ++i) th.emplace_back([&rcs, &f, g, i] { rcs[i] = f(g->subs[i], i); });
-    rcs[0] = f(g->subs[0], 0);
+    // a shard's body never lets an exception leave its thread (that would be std::terminate inside a ccall)
+    auto body = [&rcs, &f, g](int i) { rcs[i] = kr_guard(g->subs[i], "shard thread", [&] { return f(g->subs[i], i); }); };
+    try {
+        for (int i = 1; i < P; ++i) th.emplace_back(body, i);
+    } catch (...) {   // std::system_error: could not start a thread -- the shards already running are joined before the error leaves
+        for (auto &t : th) t.join();
+        throw;
+    }
+    body(0);
     for (auto &t : th) t.join();
     for (int i = 0; i < P; ++i)
         if (rcs[i] != KR_OK) return fail(g, rcs[i], "shard %d of %d (device %d): %s", i, P, g->subs[i]->device, g->subs[i]->err.c_str());
@@ -1848,6 +1966,7 @@ static int group_create(const kr_config *cfg, kr_handle **out) {
         if (share[i] > 3) return fail(nullptr, KR_ERR_UNSUPPORTED, "kr_create: device %d is listed %d times; at most 3 shards can share one GPU (hardware queues per process)", cfg->devices[i], share[i]);
     }
     kr_handle *g = new kr_handle();
+    try {
     g->cfg = *cfg;
     g->cfg.traj_generator = nullptr; g->cfg.tlist = nullptr; g->cfg.H0 = nullptr; g->cfg.Hc = nullptr; g->cfg.hc_present = nullptr;
     g->k_off.assign(P + 1, 0);
@@ -1898,96 +2017,122 @@ static int group_create(const kr_config *cfg, kr_handle **out) {
         if (rc != ncclSuccess) { fail(g, KR_ERR_HIP, "ncclCommInitAll failed: %s", r->GetErrorString(rc)); return bail(KR_ERR_HIP); }
         for (int i = 0; i < P; ++i) g->subs[i]->rccl_comm = comms[i];
     }
+    } catch (...) {   // no half-built group (and none of its shards' device memory) survives an exception
+        (void)group_destroy(g);
+        throw;
+    }
     *out = g;
     return KR_OK;
 }
 
 // ---- the exported entry points: one handle or a group ---------------------------------------------------
+// Every body runs inside kr_guard (nothing throws across the boundary).
 #define KR_NOGROUP(h, what) if (is_group(h)) return fail(h, KR_ERR_STATE, what ": not available on a handle with a device list")
+#define KR_ENTRY(h, name, ...) return kr_guard((h), name, [&]() -> int { __VA_ARGS__ })
 extern "C" int kr_create(const kr_config *cfg, kr_handle **out) {
     if (out) *out = nullptr;
-    if (cfg && out && cfg->abi_version == KR_ABI_VERSION && cfg->n_devices > 1) return group_create(cfg, out);
-    return one_create(cfg, out);
+    KR_ENTRY(nullptr, "kr_create",
+        if (cfg && out && cfg->abi_version == KR_ABI_VERSION && cfg->n_devices > 1) return group_create(cfg, out);
+        return one_create(cfg, out););
 }
-extern "C" int kr_destroy(kr_handle *h) { return is_group(h) ? group_destroy(h) : one_destroy(h); }
-extern "C" int kr_set_stream(kr_handle *h, void *st) { KR_NOGROUP(h, "kr_set_stream"); return one_set_stream(h, st); }
+extern "C" int kr_destroy(kr_handle *h) { KR_ENTRY(nullptr, "kr_destroy", return is_group(h) ? group_destroy(h) : one_destroy(h);); }
+extern "C" int kr_set_stream(kr_handle *h, void *st) { KR_ENTRY(h, "kr_set_stream", KR_NOGROUP(h, "kr_set_stream"); return one_set_stream(h, st);); }
 extern "C" int kr_enable_timing(kr_handle *h, int on) {
-    if (is_group(h)) return group_run(h, [on](kr_handle *s, int) { return one_enable_timing(s, on); });
-    return one_enable_timing(h, on);
+    KR_ENTRY(h, "kr_enable_timing",
+        if (is_group(h)) return group_run(h, [on](kr_handle *s, int) { return one_enable_timing(s, on); });
+        return one_enable_timing(h, on););
 }
-extern "C" int kr_get_timings(kr_handle *h, double *t) { return one_get_timings(is_group(h) ? h->subs[0] : h, t); }
-extern "C" int kr_get_info(kr_handle *h, int32_t *info) { return one_get_info(is_group(h) ? h->subs[0] : h, info); }
-extern "C" int kr_debug_stamps(kr_handle *h, unsigned long long *o) { return one_debug_stamps(is_group(h) ? h->subs[0] : h, o); }
-extern "C" int kr_debug_arrivals(kr_handle *h, unsigned long long *o, int words) { return one_debug_arrivals(is_group(h) ? h->subs[0] : h, o, words); }
+extern "C" int kr_get_timings(kr_handle *h, double *t) { KR_ENTRY(h, "kr_get_timings", return one_get_timings(is_group(h) ? h->subs[0] : h, t);); }
+extern "C" int kr_get_info(kr_handle *h, int32_t *info) { KR_ENTRY(h, "kr_get_info", return one_get_info(is_group(h) ? h->subs[0] : h, info);); }
+extern "C" int kr_debug_stamps(kr_handle *h, unsigned long long *o) { KR_ENTRY(h, "kr_debug_stamps", return one_debug_stamps(is_group(h) ? h->subs[0] : h, o);); }
+extern "C" int kr_debug_arrivals(kr_handle *h, unsigned long long *o, int words) { KR_ENTRY(h, "kr_debug_arrivals", return one_debug_arrivals(is_group(h) ? h->subs[0] : h, o, words);); }
+extern "C" const char *kr_plan_description(const kr_handle *h) {
+    if (!h) return "";
+    const kr_handle *s = is_group(h) ? h->subs[0] : h;
+    return s->plan_text.c_str();
+}
 extern "C" int kr_set_initial_states(kr_handle *h, const double *psi0) {
-    if (is_group(h)) { if (!psi0) return fail(h, KR_ERR_INVALID, "kr_set_initial_states: null"); return group_run(h, [h, psi0](kr_handle *s, int i) { return one_set_initial_states(s, psi0 + soff(h, i)); }); }
-    return one_set_initial_states(h, psi0);
+    KR_ENTRY(h, "kr_set_initial_states",
+        if (is_group(h)) { if (!psi0) return fail(h, KR_ERR_INVALID, "kr_set_initial_states: null"); return group_run(h, [h, psi0](kr_handle *s, int i) { return one_set_initial_states(s, psi0 + soff(h, i)); }); }
+        return one_set_initial_states(h, psi0););
 }
 extern "C" int kr_set_target_states(kr_handle *h, const double *tgt) {
-    if (is_group(h)) { if (!tgt) return fail(h, KR_ERR_INVALID, "kr_set_target_states: null"); return group_run(h, [h, tgt](kr_handle *s, int i) { return one_set_target_states(s, tgt + soff(h, i)); }); }
-    return one_set_target_states(h, tgt);
+    KR_ENTRY(h, "kr_set_target_states",
+        if (is_group(h)) { if (!tgt) return fail(h, KR_ERR_INVALID, "kr_set_target_states: null"); return group_run(h, [h, tgt](kr_handle *s, int i) { return one_set_target_states(s, tgt + soff(h, i)); }); }
+        return one_set_target_states(h, tgt););
 }
 extern "C" int kr_forward(kr_handle *h, const double *eps, double *psiT_out) {
-    if (is_group(h)) return group_run(h, [h, eps, psiT_out](kr_handle *s, int i) { return one_forward(s, eps, psiT_out ? psiT_out + soff(h, i) : nullptr); });
-    return one_forward(h, eps, psiT_out);
+    KR_ENTRY(h, "kr_forward",
+        if (is_group(h)) return group_run(h, [h, eps, psiT_out](kr_handle *s, int i) { return one_forward(s, eps, psiT_out ? psiT_out + soff(h, i) : nullptr); });
+        return one_forward(h, eps, psiT_out););
 }
 extern "C" int kr_backward(kr_handle *h, const double *eps_guess, const double *chiT) {
-    if (is_group(h)) { if (!chiT) return fail(h, KR_ERR_INVALID, "kr_backward: null"); return group_run(h, [h, eps_guess, chiT](kr_handle *s, int i) { return one_backward(s, eps_guess, chiT + soff(h, i)); }); }
-    return one_backward(h, eps_guess, chiT);
+    KR_ENTRY(h, "kr_backward",
+        if (is_group(h)) { if (!chiT) return fail(h, KR_ERR_INVALID, "kr_backward: null"); return group_run(h, [h, eps_guess, chiT](kr_handle *s, int i) { return one_backward(s, eps_guess, chiT + soff(h, i)); }); }
+        return one_backward(h, eps_guess, chiT););
 }
 extern "C" int kr_set_update_params(kr_handle *h, const double *S, const double *lambda) {
-    if (is_group(h)) return group_run(h, [S, lambda](kr_handle *s, int) { return one_set_update_params(s, S, lambda); });
-    return one_set_update_params(h, S, lambda);
+    KR_ENTRY(h, "kr_set_update_params",
+        if (is_group(h)) return group_run(h, [S, lambda](kr_handle *s, int) { return one_set_update_params(s, S, lambda); });
+        return one_set_update_params(h, S, lambda););
 }
 extern "C" int kr_update_forward(kr_handle *h, const double *eps_guess, const double *S, const double *lambda, double *eps_new_out,
                                  double *g_a_int_out, double *psiT_out) {
-    if (is_group(h))   // every shard computes the identical pulse: shard 0 delivers it
-        return group_run(h, [=](kr_handle *s, int i) { return one_update_forward(s, eps_guess, S, lambda, i == 0 ? eps_new_out : nullptr, i == 0 ? g_a_int_out : nullptr, psiT_out ? psiT_out + soff(h, i) : nullptr); });
-    return one_update_forward(h, eps_guess, S, lambda, eps_new_out, g_a_int_out, psiT_out);
+    KR_ENTRY(h, "kr_update_forward",
+        if (is_group(h))   // every shard computes the identical pulse: shard 0 delivers it
+            return group_run(h, [=](kr_handle *s, int i) { return one_update_forward(s, eps_guess, S, lambda, i == 0 ? eps_new_out : nullptr, i == 0 ? g_a_int_out : nullptr, psiT_out ? psiT_out + soff(h, i) : nullptr); });
+        return one_update_forward(h, eps_guess, S, lambda, eps_new_out, g_a_int_out, psiT_out););
 }
 extern "C" int kr_iteration(kr_handle *h, const double *eps_guess, const double *chiT, const double *S, const double *lambda,
                             double *eps_new_out, double *g_a_int_out, double *psiT_out) {
-    if (is_group(h)) {
-        if (!chiT) return fail(h, KR_ERR_INVALID, "kr_iteration: null");
-        return group_run(h, [=](kr_handle *s, int i) { return one_iteration(s, eps_guess, chiT + soff(h, i), S, lambda, i == 0 ? eps_new_out : nullptr, i == 0 ? g_a_int_out : nullptr, psiT_out ? psiT_out + soff(h, i) : nullptr); });
-    }
-    return one_iteration(h, eps_guess, chiT, S, lambda, eps_new_out, g_a_int_out, psiT_out);
+    KR_ENTRY(h, "kr_iteration",
+        if (is_group(h)) {
+            if (!chiT) return fail(h, KR_ERR_INVALID, "kr_iteration: null");
+            return group_run(h, [=](kr_handle *s, int i) { return one_iteration(s, eps_guess, chiT + soff(h, i), S, lambda, i == 0 ? eps_new_out : nullptr, i == 0 ? g_a_int_out : nullptr, psiT_out ? psiT_out + soff(h, i) : nullptr); });
+        }
+        return one_iteration(h, eps_guess, chiT, S, lambda, eps_new_out, g_a_int_out, psiT_out););
 }
 // device-resident chain on a group: the pulse pointers must be readable and writable from every listed device (memory of
 // one of them -- peer access among the listed devices is enabled at kr_create -- or managed memory); all shards write the
 // identical updated pulse
 extern "C" int kr_forward_dev(kr_handle *h, const void *eps_dev) {
-    if (is_group(h)) return group_run(h, [eps_dev](kr_handle *s, int) { return one_forward_dev(s, eps_dev); });
-    return one_forward_dev(h, eps_dev);
+    KR_ENTRY(h, "kr_forward_dev",
+        if (is_group(h)) return group_run(h, [eps_dev](kr_handle *s, int) { return one_forward_dev(s, eps_dev); });
+        return one_forward_dev(h, eps_dev););
 }
 extern "C" int kr_iteration_functional_dev(kr_handle *h, int functional, const void *eps_guess_dev, void *eps_new_dev) {
-    if (is_group(h)) return group_run(h, [=](kr_handle *s, int) { return one_iteration_functional_dev(s, functional, eps_guess_dev, eps_new_dev); });
-    return one_iteration_functional_dev(h, functional, eps_guess_dev, eps_new_dev);
+    KR_ENTRY(h, "kr_iteration_functional_dev",
+        if (is_group(h)) return group_run(h, [=](kr_handle *s, int) { return one_iteration_functional_dev(s, functional, eps_guess_dev, eps_new_dev); });
+        return one_iteration_functional_dev(h, functional, eps_guess_dev, eps_new_dev););
 }
 extern "C" int kr_synchronize(kr_handle *h) {
-    if (is_group(h)) return group_run(h, [](kr_handle *s, int) { return one_synchronize(s); });
-    return one_synchronize(h);
+    KR_ENTRY(h, "kr_synchronize",
+        if (is_group(h)) return group_run(h, [](kr_handle *s, int) { return one_synchronize(s); });
+        return one_synchronize(h););
 }
 extern "C" int kr_final_states(kr_handle *h, double *psiT_out) {
-    if (is_group(h)) { if (!psiT_out) return fail(h, KR_ERR_INVALID, "kr_final_states: null"); return group_run(h, [h, psiT_out](kr_handle *s, int i) { return one_final_states(s, psiT_out + soff(h, i)); }); }
-    return one_final_states(h, psiT_out);
+    KR_ENTRY(h, "kr_final_states",
+        if (is_group(h)) { if (!psiT_out) return fail(h, KR_ERR_INVALID, "kr_final_states: null"); return group_run(h, [h, psiT_out](kr_handle *s, int i) { return one_final_states(s, psiT_out + soff(h, i)); }); }
+        return one_final_states(h, psiT_out););
 }
 extern "C" int kr_taus(kr_handle *h, double *tau_out) {
-    if (is_group(h)) { if (!tau_out) return fail(h, KR_ERR_INVALID, "kr_taus: null"); return group_run(h, [h, tau_out](kr_handle *s, int i) { return one_taus(s, tau_out + 2 * (size_t)h->k_off[i]); }); }
-    return one_taus(h, tau_out);
+    KR_ENTRY(h, "kr_taus",
+        if (is_group(h)) { if (!tau_out) return fail(h, KR_ERR_INVALID, "kr_taus: null"); return group_run(h, [h, tau_out](kr_handle *s, int i) { return one_taus(s, tau_out + 2 * (size_t)h->k_off[i]); }); }
+        return one_taus(h, tau_out););
 }
-extern "C" int kr_g_a_int(kr_handle *h, double *out) { return one_g_a_int(is_group(h) ? h->subs[0] : h, out); }
+extern "C" int kr_g_a_int(kr_handle *h, double *out) { KR_ENTRY(h, "kr_g_a_int", return one_g_a_int(is_group(h) ? h->subs[0] : h, out);); }
 extern "C" int kr_read_storage(kr_handle *h, int which, int k, int n, double *out) {
-    if (is_group(h)) {
-        if (k < 0 || k >= h->cfg.K) return fail(h, KR_ERR_INVALID, "kr_read_storage: k = %d out of range", k);
-        int i = 0;
-        while (k >= h->k_off[i + 1]) ++i;
-        const int rc = one_read_storage(h->subs[i], which, k - h->k_off[i], n, out);
-        return rc == KR_OK ? rc : fail(h, rc, "%s", h->subs[i]->err.c_str());
-    }
-    return one_read_storage(h, which, k, n, out);
+    KR_ENTRY(h, "kr_read_storage",
+        if (is_group(h)) {
+            if (k < 0 || k >= h->cfg.K) return fail(h, KR_ERR_INVALID, "kr_read_storage: k = %d out of range", k);
+            int i = 0;
+            while (k >= h->k_off[i + 1]) ++i;
+            const int rc = one_read_storage(h->subs[i], which, k - h->k_off[i], n, out);
+            return rc == KR_OK ? rc : fail(h, rc, "%s", h->subs[i]->err.c_str());
+        }
+        return one_read_storage(h, which, k, n, out););
 }
-extern "C" int kr_rccl_init(kr_handle *h, const void *id) { KR_NOGROUP(h, "kr_rccl_init"); return one_rccl_init(h, id); }
-extern "C" int kr_set_exchange_callback(kr_handle *h, kr_allreduce_fn fn, void *ctx) { KR_NOGROUP(h, "kr_set_exchange_callback"); return one_set_exchange_callback(h, fn, ctx); }
-extern "C" int kr_ipc_export(kr_handle *h, void *o) { KR_NOGROUP(h, "kr_ipc_export"); return one_ipc_export(h, o); }
-extern "C" int kr_ipc_connect(kr_handle *h, const void *a) { KR_NOGROUP(h, "kr_ipc_connect"); return one_ipc_connect(h, a); }
+extern "C" int kr_rccl_init(kr_handle *h, const void *id) { KR_ENTRY(h, "kr_rccl_init", KR_NOGROUP(h, "kr_rccl_init"); return one_rccl_init(h, id);); }
+extern "C" int kr_set_exchange_callback(kr_handle *h, kr_allreduce_fn fn, void *ctx) { KR_ENTRY(h, "kr_set_exchange_callback", KR_NOGROUP(h, "kr_set_exchange_callback"); return one_set_exchange_callback(h, fn, ctx);); }
+extern "C" int kr_ipc_export(kr_handle *h, void *o) { KR_ENTRY(h, "kr_ipc_export", KR_NOGROUP(h, "kr_ipc_export"); return one_ipc_export(h, o);); }
+extern "C" int kr_ipc_connect(kr_handle *h, const void *a) { KR_ENTRY(h, "kr_ipc_connect", KR_NOGROUP(h, "kr_ipc_connect"); return one_ipc_connect(h, a);); }

@@ -16,7 +16,7 @@ from . import _capi as capi
 class HipEngine:
     def __init__(self, H0, Hc, tlist, K, *, hc_present=None, traj_generator=None, store_fw=True, prop_tol=0.0,
                  device=-1, rank=0, world=1, K_global=0, exchange=0, prop_method=0, max_workgroups=0, devices=None,
-                 control_poly=None):
+                 control_poly=None, spin_timeout_ms=0):
         """H0 (N,N) and Hc (L,N,N) for a generator shared by all trajectories, or H0 (G,N,N), Hc (G,L,N,N)
         with traj_generator[k] in 0..G-1 for per-trajectory generators (control_derivs[k][l],
         /root/reference/src/workspace.jl:74)."""
@@ -66,6 +66,7 @@ class HipEngine:
             cfg.n_devices = len(devices)
             for i, d in enumerate(devices):
                 cfg.devices[i] = int(d)
+        cfg.spin_timeout_ms = int(spin_timeout_ms)   # bound of the in-kernel spins; 0 = default 4000 ms
         self._cb = None
         self._poly = None
         if control_poly is not None:   # f_l(x) = sum_p control_poly[l][p] x^p  (non-linear controls, static part)
@@ -224,6 +225,11 @@ class HipEngine:
         a = (C.c_uint64 * (8 * workgroups))()
         self._chk(self._lib.kr_debug_arrivals(self._h, a, 8 * workgroups))
         return np.array(a, dtype=np.uint64).reshape(workgroups, 2, 4)
+
+    def plan(self):
+        """kr_plan_description: one line naming the kernels, grid and exchange of this handle (and why, if not the persistent ones)."""
+        msg = self._lib.kr_plan_description(self._h)
+        return msg.decode() if msg else ""
 
     def info(self):
         a = (C.c_int32 * 16)()

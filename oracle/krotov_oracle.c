@@ -97,10 +97,8 @@ static int zsolve(int n, zc *P, zc *Q) {
     return 0;
 }
 
-/* E = exp(A).  Higham (2005) scaling and squaring, Pade orders 3,5,7,9,13. */
-int orc_expm(int n, const double *A_in, double *E_out) {
-    const zc *A = (const zc *)A_in;
-    zc *E = (zc *)E_out;
+/* E = exp(A).  Higham (2005) scaling and squaring, Pade orders 3,5,7,9,13.  W: caller's workspace of 7 n*n complex. */
+static int expm_ws(int n, const zc *A, zc *E, zc *W) {
     static const double b3[] = {120., 60., 12., 1.};
     static const double b5[] = {30240., 15120., 3360., 420., 30., 1.};
     static const double b7[] = {17297280., 8648640., 1995840., 277200., 25200., 1512., 56., 1.};
@@ -114,8 +112,6 @@ int orc_expm(int n, const double *A_in, double *E_out) {
                                    9.504178996162932e-1, 2.097847961257068e0,
                                    5.371920351148152e0};
     size_t nn = (size_t)n * n;
-    zc *W = (zc *)malloc(sizeof(zc) * nn * 7);
-    if (!W) return -2;
     zc *A2 = W, *A4 = W + nn, *A6 = W + 2 * nn, *U = W + 3 * nn, *V = W + 4 * nn,
        *T = W + 5 * nn, *As = W + 6 * nn;
     double nA = norm1(n, A);
@@ -168,6 +164,13 @@ int orc_expm(int n, const double *A_in, double *E_out) {
         zgemm_nn(n, E, E, T);
         memcpy(E, T, sizeof(zc) * nn);
     }
+    return rc;
+}
+
+int orc_expm(int n, const double *A_in, double *E_out) {
+    zc *W = (zc *)malloc(sizeof(zc) * (size_t)n * n * 7);
+    if (!W) return -2;
+    int rc = expm_ws(n, (const zc *)A_in, (zc *)E_out, W);
     free(W);
     return rc;
 }
@@ -219,18 +222,27 @@ static int step_all(int n, int NT, int K, int L, const zc *H0, const zc *Hc, con
         }
         free(A);
     } else {
-#pragma omp parallel for num_threads(nthreads) schedule(static)
-        for (int k = 0; k < K; ++k) {
-            zc *A = (zc *)malloc(sizeof(zc) * nn * 2);
-            zc *U = A + nn;
-            zc y[n];
-            build_arg(n, L, H0, Hc, eps, NT, step, sdt, adj, A);
-            if (orc_expm(n, (double *)A, (double *)U) != 0) {
+        /* one workspace per THREAD (argument, propagator, 7 Pade matrices, result vector), not one malloc per trajectory per
+         * step: the allocator's lock was what limited the threaded variant (round-2 review) */
+#pragma omp parallel num_threads(nthreads)
+        {
+            zc *A = (zc *)malloc(sizeof(zc) * (nn * 9 + (size_t)n));
+            zc *U = A + nn, *W = A + 2 * nn, *y = A + 9 * nn;
+#pragma omp for schedule(static)
+            for (int k = 0; k < K; ++k) {
+                if (!A) {
 #pragma omp atomic write
-                rc = -1;
+                    rc = -2;
+                    continue;
+                }
+                build_arg(n, L, H0, Hc, eps, NT, step, sdt, adj, A);
+                if (expm_ws(n, A, U, W) != 0) {
+#pragma omp atomic write
+                    rc = -1;
+                }
+                matvec(n, U, state + (size_t)k * n, y);
+                memcpy(state + (size_t)k * n, y, sizeof(zc) * n);
             }
-            matvec(n, U, state + (size_t)k * n, y);
-            memcpy(state + (size_t)k * n, y, sizeof(zc) * n);
             free(A);
         }
     }

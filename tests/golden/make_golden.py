@@ -66,8 +66,33 @@ def main():
     eps_new, ga, psiT1, X, Phi = o.iteration(H0, Hc, tlist, eps, S, lam, psi0, chiT)
     np.savez(os.path.join(HERE, "nonhermitian_n8.npz"), H0=H0, Hc=Hc, tlist=tlist, eps=eps, S=S, lam=lam, psi0=psi0,
              tgt=tgt, psiT0=psiT, chiT=chiT, eps_new=eps_new, g_a_int=ga, psiT1=psiT1, X0=X[0], X_mid=X[NT // 2])
+    dump_flat("hermitian_n16")
+    dump_flat("nonhermitian_n8")
     print("golden fixtures written to", HERE)
 
 
+def dump_flat(name):
+    """The same fixture as a flat little-endian binary in the C ABI's memory layout (include/krotov_hip.h), for consumers that
+    cannot read .npz -- tests/abi_consumer.c, the plain-C99 stand-in for the ccall binding:
+        int32  magic 0x4B52474C ("KRGL"), N, NT, K, L, 0, 0, 0
+        double tlist[NT+1], H0[N*N] complex COLUMN-major, Hc[L][N*N] complex column-major, eps[L][NT], S[L][NT], lam[L],
+               psi0[K][N] complex, chiT[K][N], psiT0[K][N], eps_new[L][NT], g_a_int[L], psiT1[K][N], X0[K][N], X_mid[K][N]"""
+    g = np.load(os.path.join(HERE, name + ".npz"))
+    N, L = g["H0"].shape[0], g["Hc"].shape[0]
+    NT, K = g["eps"].shape[1], g["psi0"].shape[0]
+    with open(os.path.join(HERE, name + ".bin"), "wb") as f:
+        np.array([0x4B52474C, N, NT, K, L, 0, 0, 0], "<i4").tofile(f)
+        g["tlist"].astype("<f8").tofile(f)
+        np.ascontiguousarray(g["H0"].T).astype("<c16").tofile(f)                      # column-major
+        np.ascontiguousarray(np.swapaxes(g["Hc"], -1, -2)).astype("<c16").tofile(f)
+        for key, dt in (("eps", "<f8"), ("S", "<f8"), ("lam", "<f8"), ("psi0", "<c16"), ("chiT", "<c16"), ("psiT0", "<c16"),
+                        ("eps_new", "<f8"), ("g_a_int", "<f8"), ("psiT1", "<c16"), ("X0", "<c16"), ("X_mid", "<c16")):
+            np.ascontiguousarray(g[key]).astype(dt).tofile(f)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "flat":      # only re-dump the flat binaries from the committed .npz files
+        dump_flat("hermitian_n16")
+        dump_flat("nonhermitian_n8")
+    else:
+        main()

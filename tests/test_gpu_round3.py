@@ -1,0 +1,268 @@
+"""GPU tests added in round 3 (review of round 2):
+
+  * the device-resident functional chain (kr_iteration_functional_dev: tau, chi(T) on the device) pinned to the ORACLE --
+    three chained iterations of oracle/krotov_oracle.py's taus / chi_* / iteration, not the package's own host chain
+    (/root/reference/src/optimize.jl:297-302,381-386) -- on one handle and on the two-shard device list;
+  * BASELINE config 4 at FULL size on one GPU (N=64, N_T=1000, K=1024): size-independent properties;
+  * J_T_sm across two ranks when the carrier is the host callback (the tau sum travels through it as well);
+  * the boundary hardening: configurable spin bound, a device list of one entry, kr_plan_description.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import krotov_jl_amd as kr
+from krotov_jl_amd import _capi as capi
+from krotov_jl_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TOL_PULSE, TOL_STATE, TOL_GA = 1e-10, 1e-10, 1e-9
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _oracle_chain(p, fname, iters):
+    """optimize_krotov's loop (optimize.jl:209-216) restated with the oracle only: tau -> chi(T) -> krotov_iteration."""
+    import krotov_oracle as o
+    chi_of = {"sm": o.chi_sm, "ss": o.chi_ss, "re": o.chi_re}[fname]
+    J_of = {"sm": o.J_T_sm, "ss": o.J_T_ss, "re": o.J_T_re}[fname]
+    eps = p["eps"].copy()
+    psiT, _ = o.forward(p["H0"], p["Hc"], p["tlist"], eps, p["psi0"], store=False)
+    J = []
+    ga = None
+    for _ in range(iters):
+        tau = o.taus(psiT, p["tgt"])
+        J.append(J_of(tau))
+        eps, ga, psiT, _, _ = o.iteration(p["H0"], p["Hc"], p["tlist"], eps, p["S"], p["lam"], p["psi0"], chi_of(tau, p["tgt"]))
+    tau = o.taus(psiT, p["tgt"])
+    J.append(J_of(tau))
+    return eps, ga, psiT, tau, J
+
+
+@pytest.mark.parametrize("fname,fid", [("sm", 0), ("ss", 1), ("re", 2)])
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+def test_device_functional_chain_vs_oracle_chain(fname, fid, devices):
+    """Three chained iterations with tau / chi(T) formed ON THE DEVICE against three chained ORACLE iterations."""
+    import torch
+    p = wl.dense_problem(12, 30, 10, 2, 731 + fid, 0.1, 0.5)
+    K = 10
+    eps_o, ga_o, psiT_o, tau_o, J_o = _oracle_chain(p, fname, 3)
+    assert J_o[-1] < J_o[0] and np.max(np.abs(eps_o - p["eps"])) > 1e-4      # the chain really moves the pulse
+    kw = {} if devices is None else {"devices": devices}
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, **kw) as eng:
+        eng.set_initial_states(p["psi0"])
+        eng.set_target_states(p["tgt"])
+        eng.set_update_params(p["S"], p["lam"])
+        e0 = torch.from_numpy(p["eps"].copy()).cuda()
+        e1 = torch.empty_like(e0)
+        torch.cuda.synchronize()
+        eng.forward_dev(e0.data_ptr())
+        for _ in range(3):
+            eng.iteration_functional_dev(fid, e0.data_ptr(), e1.data_ptr())
+            e0, e1 = e1, e0
+        eng.synchronize()
+        assert _rel(e0.cpu().numpy(), eps_o) < TOL_PULSE
+        assert np.max(np.abs(eng.final_states() - psiT_o)) < TOL_STATE
+        assert _rel(eng.g_a_int(), ga_o) < TOL_GA
+        assert np.max(np.abs(eng.taus() - tau_o)) < 1e-11
+
+
+def test_c4_full_size_one_gpu_properties():
+    """BASELINE config 4 as stated, on ONE GPU: N=64, N_T=1000, K=1024, L=2 (two matrix-core tiles per workgroup).  The oracle
+    would need hours, so the size-independent properties: every trajectory keeps its norm; <chi_k(t_n)|psi_k(t_n)> under the
+    GUESS pulse is the same at every n (chi is propagated by the adjoint of what propagates psi:
+    /root/reference/src/workspace.jl:69,149-161) -- sampled from the two storages; a second engine reproduces pulses and
+    states bit for bit; J_T falls monotonically over three iterations."""
+    p = wl.config("C4")
+    K, N = p["psi0"].shape
+    NT = p["eps"].shape[1]
+    assert (K, N, NT) == (1024, 64, 1000)
+    lam = np.full(2, 0.2)
+    outs = []
+    for run in range(2):
+        with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+            info = eng.info()
+            assert info["matrix_core_sweep"] == 1 and info["workgroups"] == 256 and info["generic_update"] == 0, eng.plan()
+            eng.set_initial_states(p["psi0"])
+            psiT = eng.forward(p["eps"])
+            assert np.max(np.abs(np.linalg.norm(psiT, axis=1) - 1.0)) < 1e-11
+            tau, J0, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+            if run == 0:
+                # forward storage (guess pulse) against backward storage (guess pulse): invariant overlaps
+                eng.backward(p["eps"], chiT)
+                for k in (0, 511, 1023):
+                    ref = np.vdot(chiT[k], psiT[k])
+                    for n in (0, 1, 250, 777, 1000):
+                        ov = np.vdot(eng.read_storage("bw", k, n), eng.read_storage("fw", k, n))
+                        assert abs(ov - ref) < 1e-10 * np.linalg.norm(chiT[k]), (k, n, ov, ref)   # |psi| = 1
+            eps = p["eps"].copy()
+            J = [J0]
+            for _ in range(3):
+                _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+                eps, ga, psiT = eng.iteration(eps, chiT, p["S"], lam)
+                J.append(wl.chi_and_JT("ss", psiT, p["tgt"])[1])
+            assert np.max(np.abs(np.linalg.norm(psiT, axis=1) - 1.0)) < 1e-11
+            assert all(b < a for a, b in zip(J, J[1:])), J
+            assert np.all(ga > 0.0) and np.max(np.abs(eps - p["eps"])) > 1e-4
+            # the forward storage of the update sweep ends in the final states, bit for bit
+            for k in (0, 1023):
+                assert np.array_equal(eng.read_storage("fw", k, NT), psiT[k])
+            outs.append((eps.copy(), psiT.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+# ---- J_T_sm across ranks through the host callback -------------------------------------------------------------------
+def _sm_cb_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import krotov_jl_amd as kr2
+    from krotov_jl_amd import workloads as wl2
+    from krotov_jl_amd.distributed import shard_range
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        p = wl2.dense_problem(12, 30, 10, 2, 731, 0.1, 0.5)
+        K = 10
+        a, b = shard_range(K, rank, world)
+        eng = kr2.HipEngine(p["H0"], p["Hc"], p["tlist"], b - a, device=0, rank=rank, world=world, K_global=K,
+                            exchange=capi.KR_EXCHANGE_CALLBACK)
+        counts = []
+
+        def allreduce(buf):
+            counts.append(len(buf))
+            t = torch.from_numpy(buf)       # shares memory: summed in place
+            dist.all_reduce(t)
+        eng.set_exchange_callback(allreduce)
+        eng.set_initial_states(p["psi0"][a:b])
+        eng.set_target_states(p["tgt"][a:b])
+        eng.set_update_params(p["S"], p["lam"])
+        e0 = torch.from_numpy(p["eps"].copy()).cuda()
+        e1 = torch.empty_like(e0)
+        torch.cuda.synchronize()
+        eng.forward_dev(e0.data_ptr())
+        for _ in range(3):
+            eng.iteration_functional_dev(0, e0.data_ptr(), e1.data_ptr())    # J_T_sm
+            e0, e1 = e1, e0
+        eng.synchronize()
+        q.put((rank, e0.cpu().numpy(), eng.g_a_int(), eng.final_states(), counts))
+        dist.barrier()
+        eng.close()
+        dist.destroy_process_group()
+    except Exception as exc:  # noqa: BLE001
+        q.put((rank, "ERROR: %r" % (exc,), None, None, None))
+        raise
+
+
+def test_device_chain_j_t_sm_two_ranks_callback_carrier():
+    """Round-2 advisor finding: with exchange = CALLBACK (or RCCL) and world > 1 the J_T_sm chain could not run -- it wanted
+    peer mailboxes those handles never have.  The sum of the taus now travels through the handle's own carrier (one callback
+    of 2 doubles per iteration, next to the N_T callbacks of L doubles).  Against the unsharded ORACLE chain."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_sm_cb_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = {}
+    for _ in range(2):
+        rank, eps, ga, psiT, counts = q.get(timeout=240)
+        assert not isinstance(eps, str), eps
+        got[rank] = (eps, ga, psiT, counts)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert np.array_equal(got[0][0], got[1][0])
+    assert got[0][3].count(2) >= 3 and len(got[0][3]) == 3 * (30 + 1)      # per iteration: one tau sum (2 doubles; L = 2 as well) + N_T steps
+    p = wl.dense_problem(12, 30, 10, 2, 731, 0.1, 0.5)
+    eps_o, ga_o, psiT_o, _, _ = _oracle_chain(p, "sm", 3)
+    assert _rel(got[0][0], eps_o) < TOL_PULSE and _rel(got[0][1], ga_o) < TOL_GA
+    assert np.max(np.abs(np.concatenate([got[0][2], got[1][2]]) - psiT_o)) < TOL_STATE
+
+
+# ---- boundary hardening --------------------------------------------------------------------------------------------
+def test_device_list_of_one_names_the_device():
+    p = wl.dense_problem(8, 5, 6, 1, 520, 0.1, 1.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 6, devices=[0]) as eng:
+        assert "on device 0" in eng.plan()
+        eng.set_initial_states(p["psi0"])
+        assert np.max(np.abs(np.linalg.norm(eng.forward(p["eps"]), axis=1) - 1.0)) < 1e-12
+    with pytest.raises(kr.KrotovHipError) as ei:     # (round 2: silently ran on the current device)
+        kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 6, devices=[99])
+    assert ei.value.code == capi.KR_ERR_INVALID and "out of range" in str(ei.value)
+
+
+def test_plan_description_names_kernels_and_reasons():
+    p = wl.dense_problem(16, 6, 40, 1, 530, 0.1, 1.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 40) as eng:
+        assert "kr_sweep_update" in eng.plan() and "exchange = mailbox" in eng.plan()
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 40, max_workgroups=2) as eng:      # 40 trajectories on 2 workgroups
+        assert "generic" in eng.plan() and "co-resident" in eng.plan()
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 40, spin_timeout_ms=250) as eng:
+        assert "spin bound 250 ms" in eng.plan()
+    with pytest.raises(kr.KrotovHipError):
+        kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 40, spin_timeout_ms=-1)
+
+
+def _spin_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+    import torch.distributed as dist
+    import krotov_jl_amd as kr2
+    from krotov_jl_amd import workloads as wl2
+    from krotov_jl_amd.distributed import connect_peers
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        p = wl2.dense_problem(8, 6, 8, 1, 540, 0.1, 1.0)
+        eng = kr2.HipEngine(p["H0"], p["Hc"], p["tlist"], 4, device=0, rank=rank, world=world, K_global=8, max_workgroups=64,
+                            spin_timeout_ms=300)
+        connect_peers(eng, dist)
+        eng.set_initial_states(p["psi0"][4 * rank:4 * rank + 4])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl2.chi_and_JT("ss", psiT, p["tgt"][4 * rank:4 * rank + 4], K_global=8)
+        res = None
+        if rank == 0:      # rank 1 never enters the update sweep: rank 0's kernels must give up after ~0.3 s, not hang, not 4 s
+            t0 = time.perf_counter()
+            try:
+                eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+                res = ("no error", time.perf_counter() - t0)
+            except kr2.KrotovHipError as exc:
+                res = (exc.code, time.perf_counter() - t0, str(exc))
+        dist.barrier()
+        q.put((rank, res))
+        eng.close()
+        dist.destroy_process_group()
+    except Exception as exc:  # noqa: BLE001
+        q.put((rank, "ERROR: %r" % (exc,)))
+        raise
+
+
+def test_spin_bound_is_configurable():
+    """kr_config.spin_timeout_ms (round 2: a fixed 4 s): a rank whose peer never arrives gives up after the configured bound
+    with KR_ERR_TIMEOUT and a message that names the exchange."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_spin_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert not isinstance(got[0], str) and not isinstance(got[1], str), got
+    code, secs = got[0][0], got[0][1]
+    assert code == capi.KR_ERR_TIMEOUT, got[0]
+    assert 0.25 < secs < 2.5, got[0]
+    assert "exchange" in got[0][2]
