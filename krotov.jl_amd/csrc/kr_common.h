@@ -66,7 +66,15 @@ struct KrSweepArgs {
     unsigned epoch_base;     // tags = epoch_base + n + 1
     unsigned long long spin_ticks; // bound of every in-kernel spin in s_memrealtime ticks (100 MHz); kr_config.spin_timeout_ms
     int use_mfma;            // propagator build on the matrix cores where available (NP = 64)
+    // One-XCD placement of a small update grid (kr_sweep_update, P <= 32): the launch has wg_stride * P blocks, block b works as
+    // workgroup b / wg_stride iff b % wg_stride == 0 (the others exit at once), so that -- workgroups being dealt round-robin
+    // over the 8 XCDs -- all P working groups land on ONE XCD and their per-step exchange stays in that XCD's L2 (sc0 stores,
+    // sc1 loads: 295 ns per hop against 626 ns across XCDs, profiles/r02_ubench_pingpong.txt).  Confirmed in the kernel from
+    // HW_REG_XCC_ID; any other placement keeps the replicated write-through mailbox.  1 = ordinary launch.
+    int wg_stride;
 };
+#define KR_MAIL_XTAB_OFF ((size_t)2 * KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE + 64 * 4)   // words: XCC-id table behind the mailbox + tail
+#define KR_MAIL_XTAB_WORDS 64
 
 // Taylor plan: sub-steps s and order m so that the truncation bound of exp(A), ||A|| <= theta,
 // is <= tol per step.  Same code on host and device -> identical plans everywhere.

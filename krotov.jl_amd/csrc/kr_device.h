@@ -550,7 +550,8 @@ template <> struct KrIsNoWork<KrNoWork> { static constexpr bool value = true; };
 template <int LMAX, int ROWS, int SCHED = 0, class F = KrNoWork>
 __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg, const bool writer,
                                             const int rowid, const double (&part)[LMAX], double (&total)[LMAX],
-                                            double *spart /*[LMAX][ROWS]*/, double *stot /*[LMAX+1]*/, F work = F()) {
+                                            double *spart /*[LMAX][ROWS]*/, double *stot /*[LMAX+1]*/, F work = F(),
+                                            const bool xlocal = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, P = a.P;
     // Tags count exchange events over the life of the handle (32-bit, wrapping); the buffer parity is taken from
@@ -584,13 +585,14 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             }
             tot1[l] = v;
         }
-        if (lane < 4 * KR_MAIL_REPLICAS && (lane & 3) < L) {   // lane = 4 * replica + l
+        if (lane < 4 * KR_MAIL_REPLICAS && (lane & 3) < L && (!xlocal || (unsigned)(lane >> 2) == kr_xcc_id())) {   // lane = 4 * replica + l
             double v = 0.0;
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) if (l == (lane & 3)) v = tot1[l];
             const unsigned long long *dst = a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + (lane >> 2)) * KR_MAIL_RSTRIDE + (size_t)wg * KR_SLOT_GRANULES + (lane & 3);
             const unsigned long long val = kr_slot_bits(v, phase);
-            asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
+            if (xlocal) asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(dst), "v"(val) : "memory");   // stays in this XCD's L2
+            else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
         }
     }
     if (wave != 0) { KrMidPoll<LMAX> nomid{nullptr, nullptr, 0, 0, false, false}; work(nomid); }
@@ -634,7 +636,15 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 double v = 0.0;
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) if (l == (lane & 3)) v = tot[l];
-                __hip_atomic_store(slot + (lane & 3), kr_slot_bits(v, phase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (xlocal) {   // every workgroup of this launch sits on this XCD: one replica, and the store stays in its L2
+                    if ((unsigned)(lane >> 2) == kr_xcc_id()) {
+                        const unsigned long long *dst = (const unsigned long long *)slot + (lane & 3);
+                        const unsigned long long val = kr_slot_bits(v, phase);
+                        asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(dst), "v"(val) : "memory");
+                    }
+                } else {
+                    __hip_atomic_store(slot + (lane & 3), kr_slot_bits(v, phase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
 #ifdef KR_ARRIVALS  // diagnostic build: when did every workgroup publish / complete two exchanges in the middle of the sweep
             const bool arr = a.debug != nullptr && lane == 0 && (n == a.NT / 2 || n == a.NT / 2 + 1);
@@ -773,13 +783,40 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     __shared__ double spart[LMAX * 64];
     __shared__ double stot[LMAX + 1];
 
-    const int tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    // one-XCD placement of a small grid (KrSweepArgs::wg_stride): only every wg_stride-th block works
+    const int wstride = a.wg_stride > 1 ? a.wg_stride : 1;
+    if (wstride > 1 && (blockIdx.x % wstride) != 0) return;
+    const int tid = threadIdx.x, wg = blockIdx.x / wstride, lane = tid & 63, wave = tid >> 6;
     const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const bool memwave = (wave == NW - 1);
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
     const double my_thr = kr_load_my_thr(a);
-    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x] : 0);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[wg] : 0);
+    // Did the placement work?  Every workgroup posts its XCC id behind the mailbox (zeroed in front of the launch), wave 0 reads
+    // all P entries: local iff they all carry this workgroup's id.  A workgroup that gives up waiting stays on the
+    // placement-independent path; mixed conclusions are harmless (a write-through store also updates this XCD's L2, and an
+    // sc0 store is visible to every sc1 load issued on the same XCD).
+    bool xlocal = false;
+    if (wstride > 1 && a.P <= 64) {
+        __shared__ int sxl;
+        if (wave == 0) {
+            kr_gu64 *xtab = (kr_gu64 *)(a.mail + KR_MAIL_XTAB_OFF);
+            const unsigned xcc = kr_xcc_id();
+            if (lane == 0) __hip_atomic_store(xtab + wg, (1ull << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = kr_realtime();
+            bool same = false;
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(xtab + min(lane, a.P - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((v >> 32) != 0ull)) { same = __all((unsigned)(v & 15ull) == xcc); break; }
+                if (kr_realtime() - t0 > a.spin_ticks / 64) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) sxl = same ? 1 : 0;
+        }
+        __syncthreads();
+        xlocal = (sxl != 0);
+    }
     const int rowid = tid / JQ;  // 0..63
     const int pi_ = i + i / JS;
     const int xoff = jq * (JS + 1);
@@ -952,7 +989,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 
         // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
         double du[LMAX];
-        if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot, window)) return;
+        if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot, window, xlocal)) return;
 
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 

@@ -92,6 +92,7 @@ struct kr_handle {
     unsigned long long spin_ticks = KR_SPIN_DEFAULT_TICKS;   // kr_config.spin_timeout_ms
     std::string plan_note;     // why a problem left the persistent kernels / what could not be verified
     std::string plan_text;     // kr_plan_description(): one line, written at the end of kr_create
+    int wg_stride = 1;         // one-XCD placement of a small update grid (KrSweepArgs::wg_stride)
     int sets = 1;              // tile sets a persistent workgroup time-multiplexes within a step (K beyond one set per CU)
     unsigned epoch_base = 0;
     unsigned func_epoch = 0;   // tag of the cross-rank tau sums (J_T_sm on the device, world > 1)
@@ -544,6 +545,12 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
         h->perm[k] = tile_base[g] * h->KTILE + seen[g]++;
         if (h->perm[k] != k) h->identity_perm = false;
     }
+    // Few workgroups (C2: 8): put them all on ONE XCD so that the per-step exchange stays in its L2 (KrSweepArgs::wg_stride).
+    // Only when this handle has the GPU to itself (the other XCDs' blocks exit at once, but they must be dispatched) and for the
+    // vector update kernel.  KROTOV_HIP_XCD_LOCAL=0 switches it off.
+    h->wg_stride = 1;
+    if (NP <= 64 && !h->mfma_sweep && h->P >= 2 && h->P <= 32 && maxwg == cus && env_int("KROTOV_HIP_XCD_LOCAL", 1) != 0)
+        h->wg_stride = 8;
     return KR_OK;
 }
 
@@ -987,8 +994,9 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     CHK(hipMemset(h->psiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->chiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->gint_d, 0, std::max(L, KR_LMAX_CAP) * sizeof(double)));
-    h->mail_words = (size_t)2 * KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE + 64 * 4;  // 2 buffers x 8 replicas (one per XCD) x 64 KB (kr_exchange); tail: a poll pass
-                                                                               // reads whole 64-slot chunks (kr_poll_pass)
+    h->mail_words = KR_MAIL_XTAB_OFF + KR_MAIL_XTAB_WORDS;  // 2 buffers x 8 replicas (one per XCD) x 64 KB (kr_exchange); tail: a poll pass
+                                                            // reads whole 64-slot chunks (kr_poll_pass); then the XCC-id table of the
+                                                            // one-XCD placement (kr_sweep_update)
     if ((size_t)h->P * 4 > KR_MAIL_RSTRIDE) { fail(h, KR_ERR_UNSUPPORTED, "%d workgroups do not fit one mailbox replica", h->P); return bail(KR_ERR_UNSUPPORTED); }
     CHK(alloc_mailbox(h, &h->mail_d, h->mail_words, h->P));
     CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
@@ -1023,9 +1031,9 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         const char *known = h->gen_known ? "kr_gen_known" : h->rowsplit ? "kr_rowsplit_sweep" : h->precomp ? "kr_expm + kr_sweep_apply" : "kr_sweep_known";
         static const char *const exn[] = {"auto", "mailbox", "rccl", "callback"};
         snprintf(buf, sizeof buf, "N=%d (padded %d) NT=%d K=%d (padded %d) L=%d G=%d rank %d/%d on device %d: update sweep = %s, %d workgroups x %d "
-                 "trajectories, sets per workgroup %d, R=%d, HERM=%d, economized=%d, poll_delay=%d; known-pulse sweeps = %s; exchange = %s; spin bound %.0f ms%s%s",
+                 "trajectories, sets per workgroup %d, one-XCD placement %d, R=%d, HERM=%d, economized=%d, poll_delay=%d; known-pulse sweeps = %s; exchange = %s; spin bound %.0f ms%s%s",
                  h->cfg.N, h->NP, h->cfg.NT, h->cfg.K, h->Kp, h->cfg.L, h->G, h->cfg.rank, h->cfg.world, h->device, upd, h->P, h->KTILE, h->sets,
-                 h->rowsplit ? h->R : 1, h->herm ? 1 : 0, h->econ ? 1 : 0, h->poll_delay, known, exn[h->exchange & 3], (double)h->spin_ticks / 1e5,
+                 h->wg_stride > 1 ? 1 : 0, h->rowsplit ? h->R : 1, h->herm ? 1 : 0, h->econ ? 1 : 0, h->poll_delay, known, exn[h->exchange & 3], (double)h->spin_ticks / 1e5,
                  h->plan_note.empty() ? "" : "; note: ", h->plan_note.c_str());
         h->plan_text = buf;
     }
@@ -1173,6 +1181,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.Hdense = h->Hdense_fw;
     a.dense_stride = h->dense_stride;
     a.gen_div = 1;
+    a.wg_stride = 1;
     a.wg_gen = (h->G > 1) ? h->wg_gen_d : nullptr;
     a.nrm_dev = h->nrm_d;
     a.econ = nullptr;
@@ -1494,7 +1503,10 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
         int kind = 1;
         if (h->NP <= 64) kind |= ((h->poll_delay >= 0) ? 16 : 0) | (calib_steps ? 32 : 0) | (h->herm ? 64 : 0);
         if (h->mfma_sweep) HIPCHK(h, kr_launch_mf64(h->LMAXv, h->KT / 2, kind, h->P, h->stream, &a));
-        else HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P, h->stream, &a));
+        else {
+            a.wg_stride = (h->NP <= 64) ? h->wg_stride : 1;
+            HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P * a.wg_stride, h->stream, &a));
+        }
     }
     return ev_mark(h, 2, true);
 }
