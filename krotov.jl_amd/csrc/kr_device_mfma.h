@@ -129,13 +129,22 @@ __device__ __forceinline__ void kr_mf_put(double2 *W, const int doff, const int 
 
 // CAL = 1: the same kernel under another name for the short sweeps of calibrate_exchange (krotov_hip.hip), so that profiler
 // statistics of kr_mf_update<..., 0> hold the caller's launches only.
-template <int LMAX, int TILES, int SCHED, int HERM, int CAL>
+// SETS > 1 (round 3): the workgroup time-multiplexes SETS sets of TILES tiles within a step -- K beyond 4 trajectories per CU
+// (K = 2048 / 4096 per GPU at N = 64) without leaving the persistent kernel: phase A runs set by set and ACCUMULATES the partial
+// sums, ONE exchange and ONE pulse update / H(eps_new) serve all sets, then the polynomial rounds run set by set (the products
+// D of every set stay in registers across the exchange, so the first application is free for every set).  LDS: the drift (64 KB)
+// and the Horner ping-pong are shared; per set ONE psi array and ONE chi array (no parity pair: psi(t_{n+1}) overwrites psi(t_n)
+// in place once the exchange's barriers lie behind every reader, chi(t_{n+1}) is handed over after the set's rounds), 16 KB per
+// set at two tiles -> 4 sets in 144 KB.  The general (non-HERM) variant only.
+template <int LMAX, int TILES, int SCHED, int HERM, int CAL, int SETS = 1>
 __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
+    static_assert(SETS == 1 || HERM == 0, "several sets per workgroup: general variant only");
     constexpr int KT = 2 * TILES, TW = KR_MF_TW, NW = 4;
     constexpr int CH = KT;  // 16-B elements per lane when the memory wave moves a whole tile (KT * 64 / 64)
-    __shared__ __attribute__((aligned(16))) double2 sx[2][TILES][TW];  // psi(t_n) as operand array, by parity `cur`
+    constexpr int NB = (SETS == 1) ? 2 : SETS;   // psi / chi arrays: a parity pair for one set, one array per set otherwise
+    __shared__ __attribute__((aligned(16))) double2 sx[NB][TILES][TW];  // psi(t_n) as operand array (SETS = 1: by parity `cur`)
     __shared__ __attribute__((aligned(16))) double2 sy[2][TILES][TW];  // Horner vectors, ping-pong
-    __shared__ __attribute__((aligned(16))) double2 sc[2][TILES][TW];  // chi(t_k) in slot k & 1 (a matvec operand when HERM)
+    __shared__ __attribute__((aligned(16))) double2 sc[NB][TILES][TW];  // chi(t_k) (SETS = 1: in slot k & 1; a matvec operand when HERM)
     __shared__ __attribute__((aligned(16))) double2 sH0[16 * 256];     // A operands of the drift H0, [slot][tid] = {re, im} (64 KB)
     __shared__ double spart[LMAX * NW];
     __shared__ double stot[LMAX + 1];
@@ -156,9 +165,14 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x] : 0);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
-    const size_t tile_base = (size_t)wg * KT * N;  // the tile's trajectories are contiguous in every [Kp][N] slab
+    const size_t tile_base = (size_t)wg * SETS * KT * N;  // the workgroup's trajectories are contiguous in every [Kp][N] slab, set after set
+    const size_t set_stride = (size_t)KT * N;
     const int tile_elems = KT * N;
     const bool row_ok = drow < N;
+    // which psi / chi array: one set -> parity; several sets -> the set's own
+#define KR_SX_RD(st) sx[SETS == 1 ? cur : (st)]
+#define KR_SX_WR(st) sx[SETS == 1 ? (cur ^ 1) : (st)]
+#define KR_SC_AT(st, k) sc[SETS == 1 ? ((k) & 1) : (st)]
 
     // A operands (dense row-major [m][64][64], zero padded): 16 k-blocks x (re, im) per matrix; H_1..H_L in registers,
     // the drift H0 in LDS
@@ -193,25 +207,29 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     double2 cpf[CH];  // chi prefetch registers (memory wave)
 
     // initial state into registers (D layout) and LDS (packed psi and -i psi); rows >= N stay zero
-    double psi[TILES];
+    double psi[SETS][TILES];
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-        double v = 0.0;
-        if (row_ok) v = ((const double *)a.init)[(tile_base + (size_t)(2 * t + dt) * N + drow) * 2 + dc];
-        psi[t] = v;
-        kr_mf_put(sx[0][t], doff, zoff, zs, v);
-        double c0 = 0.0, c1 = 0.0;
-        if (row_ok) {
-            c0 = ((const double *)a.X)[(tile_base + (size_t)(2 * t + dt) * N + drow) * 2 + dc];              // chi(t_0)
-            if (HERM && NT > 1) c1 = ((const double *)a.X)[(slab + tile_base + (size_t)(2 * t + dt) * N + drow) * 2 + dc];  // chi(t_1)
+    for (int st = 0; st < SETS; ++st) {
+        const size_t sb = tile_base + st * set_stride;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            double v = 0.0;
+            if (row_ok) v = ((const double *)a.init)[(sb + (size_t)(2 * t + dt) * N + drow) * 2 + dc];
+            psi[st][t] = v;
+            kr_mf_put(sx[SETS == 1 ? 0 : st][t], doff, zoff, zs, v);
+            double c0 = 0.0, c1 = 0.0;
+            if (row_ok) {
+                c0 = ((const double *)a.X)[(sb + (size_t)(2 * t + dt) * N + drow) * 2 + dc];              // chi(t_0)
+                if (HERM && NT > 1) c1 = ((const double *)a.X)[(slab + sb + (size_t)(2 * t + dt) * N + drow) * 2 + dc];  // chi(t_1)
+            }
+            kr_mf_put(sc[SETS == 1 ? 0 : st][t], doff, zoff, zs, c0);
+            if (SETS == 1) kr_mf_put(sc[1][t], doff, zoff, zs, c1);
         }
-        kr_mf_put(sc[0][t], doff, zoff, zs, c0);
-        kr_mf_put(sc[1][t], doff, zoff, zs, c1);
-    }
-    if (memwave && a.store) {
+        if (memwave && a.store) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-            if (m_ok[c]) a.store[tile_base + lane + 64 * c] = a.init[tile_base + lane + 64 * c];
+            for (int c = 0; c < CH; ++c)
+                if (m_ok[c]) a.store[sb + lane + 64 * c] = a.init[sb + lane + 64 * c];
+        }
     }
     double gint[LMAX];
 #pragma unroll
@@ -251,34 +269,38 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
             for (int l = 0; l < LMAX; ++l)
                 if (l < L) { eg_nx[l] = a.eps[(size_t)l * NT + n + 1]; al_nx[l] = a.alpha[(size_t)l * NT + n + 1]; }
         }
-        // D[m][t] = packed(-i H_m psi)[this lane], m = 0 (drift), 1..L (controls)
-        double D[LMAX + 1][TILES];
+        // D[set][m][t] = packed(-i H_m psi)[this lane], m = 0 (drift), 1..L (controls)
+        double D[SETS][LMAX + 1][TILES];
         double part[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) part[l] = 0.0;
-        auto products = [&]() {   // (L is wave-uniform; LMAX = 4 covers L = 3 with a zero matrix)
+        auto products = [&](const int st) {   // (L is wave-uniform; LMAX = 4 covers L = 3 with a zero matrix)
             if (L == 1) {
                 double dd[2][TILES];
-                kr_mf_multi<TILES, 2, true, false>(sH0, Hr, Hi, &sx[cur][0][0], boff, kb0, dd);
+                kr_mf_multi<TILES, 2, true, false>(sH0, Hr, Hi, &KR_SX_RD(st)[0][0], boff, kb0, dd);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    D[0][t] = dd[0][t]; D[1][t] = dd[1][t];
+                    D[st][0][t] = dd[0][t]; D[st][1][t] = dd[1][t];
 #pragma unroll
-                    for (int l = 1; l < LMAX; ++l) D[1 + l][t] = 0.0;
+                    for (int l = 1; l < LMAX; ++l) D[st][1 + l][t] = 0.0;
                 }
             } else {
-                kr_mf_multi<TILES, 1 + LMAX, true, false>(sH0, Hr, Hi, &sx[cur][0][0], boff, kb0, D);
+                kr_mf_multi<TILES, 1 + LMAX, true, false>(sH0, Hr, Hi, &KR_SX_RD(st)[0][0], boff, kb0, D[st]);
             }
         };
         if (!HERM) {
-            // ---- phase A: Im<chi|H_l|psi> = Im(conj(chi) a), a = H_l psi = i D  ->  chi_r D_r + chi_i D_i, lane by lane ----
-            products();
+            // ---- phase A: Im<chi|H_l|psi> = Im(conj(chi) a), a = H_l psi = i D  ->  chi_r D_r + chi_i D_i, lane by lane;
+            //      set after set into the same partial sums ----
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                const double chc = sc[n & 1][t][doff].y;
+            for (int st = 0; st < SETS; ++st) {
+                products(st);
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l)
-                    if (l < L && ((gx.present >> l) & 1u)) part[l] = fma(chc, D[1 + l][t], part[l]);
+                for (int t = 0; t < TILES; ++t) {
+                    const double chc = KR_SC_AT(st, n)[t][doff].y;
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l)
+                        if (l < L && ((gx.present >> l) & 1u)) part[l] = fma(chc, D[st][1 + l][t], part[l]);
+                }
             }
         } else {
             // ---- Im<H_l chi|psi> = Im(conj(c) psi), c = H_l chi = i cl  ->  -(cl_r psi_r + cl_i psi_i) ----
@@ -286,14 +308,14 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
             for (int t = 0; t < TILES; ++t) {
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l)
-                    if (l < L && ((gx.present >> l) & 1u)) part[l] = fma(-cl[l][t], psi[t], part[l]);
+                    if (l < L && ((gx.present >> l) & 1u)) part[l] = fma(-cl[l][t], psi[0][t], part[l]);
             }
         }
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) part[l] = kr_wave_sum(part[l]);   // fixed order: bitwise reproducible
         auto window = [&](auto &mid) {
             if (HERM) {
-                products();   // (no early poll pass here -- mid() of kr_exchange: measured +0.2 % at two tiles, +0.9 % at one)
+                products(0);   // (no early poll pass here -- mid() of kr_exchange: measured +0.2 % at two tiles, +0.9 % at one)
                 (void)mid;
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l)
@@ -332,89 +354,95 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
 
         // ---- psi <- exp(-i H(eps_new) dt) psi.  -i H(eps_new) psi = D_0 + sum e_l D_l is known already, so the first
         //      sub-step costs m - 1 products:  psi' = psi + y_1,  y_m = v,  y_{j-1} = v + (fs / j)(-i H y_j),  v = fs (-i H psi)
-        double v[TILES], y[TILES];
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            double w = D[0][t];
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) w = fma(e[l], D[1 + l][t], w);
-            v[t] = fs * w;
-            y[t] = v[t];
-            if (m > 1) kr_mf_put(sy[0][t], doff, zoff, zs, v[t]);
-        }
-        // A operands of H(eps_new)
-        double Er[16], Ei[16];
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            const double2 h0 = sH0[kb * 256 + tid];
-            double r = h0.x, im = h0.y;
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) { r = fma(e[l], Hr[l][kb], r); im = fma(e[l], Hi[l][kb], im); }
-            Er[kb] = r;
-            Ei[kb] = im;
-        }
-        // memory wave: start fetching chi(t_{n+1}) (HERM: chi(t_{n+2})); it lands while the Taylor rounds run
-        if (memwave && n + 1 + HERM < NT) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                cpf[c] = a.X[(size_t)(n + 1 + HERM) * slab + tile_base + min(lane + 64 * c, tile_elems - 1)];
-        }
-        // Rounds j = m .. 2.  Every wave has written its own rows of the current Horner vector; the workgroup barrier of the
-        // round sits inside kr_mf_apply<.., OWNFIRST> (behind the requests for the wave's own rows).  No hazard on the
-        // ping-pong buffers: a wave writes buffer wb in round j only after that barrier, which the others reach after their
-        // reads of the same buffer in round j + 1.
-        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB1 += t - t_prev; }
-        int wb = 1;
-        for (int j = m; j >= 2; --j) {
-            const double f = fs * kr_rinv_lane(my_g, j);
-            double d[TILES];
-            kr_mf_apply<TILES, true>(Er, Ei, &sy[wb ^ 1][0][0], boff, kb0, d);   // (own rows first: 1016 -> 969 cycles per round at one tile, a wash at two)
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                y[t] = fma(f, d[t], v[t]);
-                if (j > 2) kr_mf_put(sy[wb][t], doff, zoff, zs, y[t]);
-            }
-            wb ^= 1;
-        }
-        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB2 += t - t_prev; }
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            psi[t] = fma(eco.a1, y[t], eco.a0 * psi[t]);   // (Taylor: a0 = a1 = 1)
-            kr_mf_put(sx[cur ^ 1][t], doff, zoff, zs, psi[t]);
-        }
+        double Er[16], Ei[16];   // A operands of H(eps_new): formed ONCE per step (behind the first set's first LDS write), whatever the number of sets
         // chi(t_{n+1}) (HERM: chi(t_{n+2})) from the prefetch registers into LDS (a macro, not a lambda: captured by
         // reference the prefetch registers would become a stack array)
-#define KR_MF_HAND_OVER_CHI()                                                                                          \
+#define KR_MF_HAND_OVER_CHI(st_)                                                                                       \
         if (memwave && n + 1 + HERM < NT) {                                                                            \
-            const int par = (n + 1 + HERM) & 1;                                                                        \
+            double2 *scw_ = &KR_SC_AT(st_, n + 1 + HERM)[0][0];                                                        \
             _Pragma("unroll") for (int c = 0; c < CH; ++c) {                                                           \
                 if (m_ok[c]) {   /* columns re, im of the element: {(-i chi)_c, chi_c} */                             \
-                    (&sc[par][0][0])[m_pos[c]] = make_double2(cpf[c].y, cpf[c].x);                                     \
-                    (&sc[par][0][0])[m_pos[c] + 1] = make_double2(-cpf[c].x, cpf[c].y);                                \
+                    scw_[m_pos[c]] = make_double2(cpf[c].y, cpf[c].x);                                                 \
+                    scw_[m_pos[c] + 1] = make_double2(-cpf[c].x, cpf[c].y);                                            \
                 }                                                                                                      \
             }                                                                                                          \
         }
-        if (s == 1) { KR_MF_HAND_OVER_CHI() }
-        __syncthreads();
-        cur ^= 1;
-        for (int sub = 1; sub < s; ++sub) {  // further sub-steps (only when ||H dt|| > KR_THETA_MAX): plain Horner from psi
-            int w2 = 0;
-            for (int j = m; j >= 1; --j) {
-                const double f = fs * kr_rinv_lane(my_rinv, j);
+#pragma unroll
+        for (int st = 0; st < SETS; ++st) {
+            const size_t sb = tile_base + st * set_stride;
+            double v[TILES], y[TILES];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                double w = D[st][0][t];
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) w = fma(e[l], D[st][1 + l][t], w);
+                v[t] = fs * w;
+                y[t] = v[t];
+                if (m > 1) kr_mf_put(sy[0][t], doff, zoff, zs, v[t]);
+            }
+            if (st == 0) {
+#pragma unroll
+                for (int kb = 0; kb < 16; ++kb) {
+                    const double2 h0 = sH0[kb * 256 + tid];
+                    double r = h0.x, im = h0.y;
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) { r = fma(e[l], Hr[l][kb], r); im = fma(e[l], Hi[l][kb], im); }
+                    Er[kb] = r;
+                    Ei[kb] = im;
+                }
+            }
+            // memory wave: start fetching this set's chi(t_{n+1}) (HERM: chi(t_{n+2})); it lands while the set's rounds run
+            if (memwave && n + 1 + HERM < NT) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    cpf[c] = a.X[(size_t)(n + 1 + HERM) * slab + sb + min(lane + 64 * c, tile_elems - 1)];
+            }
+            // Rounds j = m .. 2.  Every wave has written its own rows of the current Horner vector; the workgroup barrier of the
+            // round sits inside kr_mf_apply<.., OWNFIRST> (behind the requests for the wave's own rows).  No hazard on the
+            // ping-pong buffers: a wave writes buffer wb in round j only after that barrier, which the others reach after their
+            // reads of the same buffer in round j + 1.
+            if (stamp && st == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB1 += t - t_prev; }
+            int wb = 1;
+            for (int j = m; j >= 2; --j) {
+                const double f = fs * kr_rinv_lane(my_g, j);
                 double d[TILES];
-                if (j == m) kr_mf_apply<TILES>(Er, Ei, &sx[cur][0][0], boff, kb0, d);
-                else kr_mf_apply<TILES>(Er, Ei, &sy[w2 ^ 1][0][0], boff, kb0, d);
+                kr_mf_apply<TILES, true>(Er, Ei, &sy[wb ^ 1][0][0], boff, kb0, d);   // (own rows first: 1016 -> 969 cycles per round at one tile, a wash at two)
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    const double yn = fma(f, d[t], psi[t]);
-                    if (j > 1) kr_mf_put(sy[w2][t], doff, zoff, zs, yn);
-                    else { psi[t] = yn; kr_mf_put(sx[cur ^ 1][t], doff, zoff, zs, yn); }
+                    y[t] = fma(f, d[t], v[t]);
+                    if (j > 2) kr_mf_put(sy[wb][t], doff, zoff, zs, y[t]);
                 }
-                if (j == 1 && sub == s - 1) { KR_MF_HAND_OVER_CHI() }
-                __syncthreads();
-                w2 ^= 1;
+                wb ^= 1;
             }
-            cur ^= 1;
+            if (stamp && st == SETS - 1) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB2 += t - t_prev; }
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                psi[st][t] = fma(eco.a1, y[t], eco.a0 * psi[st][t]);   // (Taylor: a0 = a1 = 1)
+                kr_mf_put(KR_SX_WR(st)[t], doff, zoff, zs, psi[st][t]);   // (several sets: in place -- its last readers were phase A)
+            }
+            if (s == 1) { KR_MF_HAND_OVER_CHI(st) }
+            __syncthreads();   // the set's psi / chi are complete; the Horner ping-pong is free for the next set
+            if (SETS == 1) cur ^= 1;
+            for (int sub = 1; sub < s; ++sub) {  // further sub-steps (only when ||H dt|| > KR_THETA_MAX): plain Horner from psi
+                int w2 = 0;
+                for (int j = m; j >= 1; --j) {
+                    const double f = fs * kr_rinv_lane(my_rinv, j);
+                    double d[TILES];
+                    if (j == m) kr_mf_apply<TILES>(Er, Ei, &KR_SX_RD(st)[0][0], boff, kb0, d);
+                    else kr_mf_apply<TILES>(Er, Ei, &sy[w2 ^ 1][0][0], boff, kb0, d);
+                    if (SETS > 1 && m == 1) __syncthreads();   // in-place psi array: every wave has read it before anyone overwrites
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        const double yn = fma(f, d[t], psi[st][t]);
+                        if (j > 1) kr_mf_put(sy[w2][t], doff, zoff, zs, yn);
+                        else { psi[st][t] = yn; kr_mf_put(KR_SX_WR(st)[t], doff, zoff, zs, yn); }
+                    }
+                    if (j == 1 && sub == s - 1) { KR_MF_HAND_OVER_CHI(st) }
+                    __syncthreads();
+                    w2 ^= 1;
+                }
+                if (SETS == 1) cur ^= 1;
+            }
         }
 #undef KR_MF_HAND_OVER_CHI
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB += t - t_prev; t_prev = t; }
@@ -422,8 +450,12 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         // memory wave: forward storage slot n+1 <- psi(t_{n+1}) (coalesced 16-B stores from LDS)
         if (memwave && a.store) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (m_ok[c]) a.store[(size_t)(n + 1) * slab + tile_base + lane + 64 * c] = make_double2((&sx[cur][0][0])[m_pos[c]].y, (&sx[cur][0][0])[m_pos[c] + 1].y);
+            for (int st = 0; st < SETS; ++st) {
+                const double2 *sxr = &KR_SX_RD(st)[0][0];
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (m_ok[c]) a.store[(size_t)(n + 1) * slab + tile_base + st * set_stride + lane + 64 * c] = make_double2(sxr[m_pos[c]].y, sxr[m_pos[c] + 1].y);
+            }
         }
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tS += t - t_prev; t_prev = t; }
     }
@@ -433,13 +465,18 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     }
     if (a.fin && row_ok) {
 #pragma unroll
-        for (int t = 0; t < TILES; ++t)
-            ((double *)a.fin)[(tile_base + (size_t)(2 * t + dt) * N + drow) * 2 + dc] = psi[t];
+        for (int st = 0; st < SETS; ++st)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                ((double *)a.fin)[(tile_base + st * set_stride + (size_t)(2 * t + dt) * N + drow) * 2 + dc] = psi[st][t];
     }
     if (wg == 0 && tid == 0) {
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
     }
+#undef KR_SX_RD
+#undef KR_SX_WR
+#undef KR_SC_AT
 }
 
 // =============================================================================================
@@ -566,11 +603,24 @@ static hipError_t kr_launch_mfma64(int tiles, int kind, int grid, hipStream_t s,
         }                                                                                                          \
         return hipGetLastError();                                                                                  \
     }
+    // several sets per workgroup (tiles argument = tiles | sets << 8): two tiles, general variant only
+#define KR_CASE_S(ST)                                                                                              \
+    if (tiles == (2 | (ST << 8))) {                                                                                \
+        switch (v & 5) {                                                                                           \
+        case 0: kr_launch_kernel((kr_mf_update<LM, 2, 0, 0, 0, ST>), grid, 256, 0, s, *a); break;    \
+        case 1: kr_launch_kernel((kr_mf_update<LM, 2, 1, 0, 0, ST>), grid, 256, 0, s, *a); break;    \
+        case 4: kr_launch_kernel((kr_mf_update<LM, 2, 0, 0, 1, ST>), grid, 256, 0, s, *a); break;    \
+        default: kr_launch_kernel((kr_mf_update<LM, 2, 1, 0, 1, ST>), grid, 256, 0, s, *a); break;   \
+        }                                                                                                          \
+        return hipGetLastError();                                                                                  \
+    }
 #ifdef KR_MF_ONLY_TILES
     KR_CASE_M(KR_MF_ONLY_TILES)
 #else
     KR_CASE_M(1) KR_CASE_M(2)   // (4 tiles: the vector arrays + H0 exceed the CU's LDS and the accumulators spill)
+    KR_CASE_S(2) KR_CASE_S(4)
 #endif
 #undef KR_CASE_M
+#undef KR_CASE_S
     return hipErrorInvalidValue;
 }

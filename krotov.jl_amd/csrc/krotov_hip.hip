@@ -520,11 +520,18 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             while (ktm < 4 && kt_forced == 0 && tiles_for(ktm) > maxwg) ktm <<= 1;
             h->mfma_sweep = true;
             kt = ktm;
+            // more trajectories than 4 per CU: the workgroup time-multiplexes several sets of two tiles within a step
+            // (kr_mf_update<.., SETS>): K = 2048 / 4096 per GPU stay on the persistent kernel.  KROTOV_HIP_SETS fixes the count.
+            if (kt == 4) {
+                const int want_sets = env_int("KROTOV_HIP_SETS", 0);
+                if (want_sets == 1 || want_sets == 2 || want_sets == 4) h->sets = want_sets;
+                else while (h->sets < 4 && tiles_for(kt * h->sets) > maxwg) h->sets <<= 1;
+            }
         }
     }
     h->KT = kt;
-    h->KTILE = h->SG * kt;
-    h->P = tiles_for(kt);
+    h->KTILE = h->SG * kt * h->sets;
+    h->P = tiles_for(kt * h->sets);
     if (h->P > maxwg)
         return fail(h, KR_ERR_UNSUPPORTED, "K = %d trajectories (%d generators) need %d co-resident workgroups (> %d CUs) at NP = %d", c.K, h->G, h->P, maxwg, NP);
     h->Kp = h->P * h->KTILE;
@@ -583,6 +590,7 @@ static void decide_herm(kr_handle *h, const kr_config *cfg) {
     // (matrix-core sweep: with one tile per workgroup the window hides phase A -- K = 512: 8.0k against ~8.9k cycles for
     //  dot + exchange --, with two tiles its five products outlast the exchange: C4 11.74 vs 11.35 us per step)
     h->herm = (mode == 2) || (mode == 1 && (h->mfma_sweep ? h->KT == 2 : h->KT == 1) && h->P >= 64 && h->NP <= 64);
+    if (h->sets > 1) h->herm = false;   // several sets per workgroup: general variant only
     if (h->mfma_sweep && h->LMAXv == 4 && h->KT == 4) h->herm = false;   // that instantiation spills (212 B): general variant
     if (h->rowsplit || h->NP > 64) h->herm = false;
     for (int g = 0; g < G && h->herm; ++g) {
@@ -634,7 +642,7 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
             else if (sched) break;
             q.on = 1; q.blocks_per_cu = -2;
             if (h->rowsplit) (void)h->launch_rs(h->LMAXv, h->NR, 1, h->P, nullptr, &dummy);
-            else if (h->mfma_sweep) (void)kr_launch_mf64(h->LMAXv, h->KT / 2, kind, h->P, nullptr, &dummy);
+            else if (h->mfma_sweep) (void)kr_launch_mf64(h->LMAXv, (h->KT / 2) | (h->sets > 1 ? h->sets << 8 : 0), kind, h->P, nullptr, &dummy);
             else (void)h->launch(h->LMAXv, h->KT, kind, h->P, nullptr, &dummy);
             q.on = 0;
             if (q.blocks_per_cu < 0) unknown = true;   // -2: this launcher has no query mode; -1: the runtime's query failed
@@ -1434,7 +1442,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
             int kt_a = (h->KT % 2 == 0) ? std::min(h->KT, 4) : 2;
             const int want_a = env_int("KROTOV_HIP_MFMA_APPLY_KT", 0);   // (tuning knob: 2 or 4 trajectories per workgroup)
             if ((want_a == 2 || want_a == 4) && h->Kp % want_a == 0 && (h->G == 1 || h->KT % want_a == 0 || want_a % h->KT == 0) && (h->G == 1 || want_a <= h->KT)) kt_a = want_a;
-            a.gen_div = std::max(1, h->KT / kt_a);
+            a.gen_div = std::max(1, h->KT * h->sets / kt_a);
             HIPCHK(h, kr_launch_mf64(2, kt_a / 2, 3, h->Kp / kt_a, h->stream, &a));
             return ev_mark(h, which_ev, true);
         }
@@ -1449,12 +1457,12 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
                 if (pick && h->Kp % (h->SG * cand) == 0) { kt_apply = cand; break; }
             }
         }
-        a.gen_div = h->KT / kt_apply;   // apply tiles per update tile (wg_gen is indexed by update tile)
+        a.gen_div = h->KT * h->sets / kt_apply;   // apply tiles per update tile (wg_gen is indexed by update tile)
         if (a.gen_div < 1) a.gen_div = 1;
         HIPCHK(h, h->launch(h->LMAXv, kt_apply, 3, h->Kp / (h->SG * kt_apply), h->stream, &a));
     } else {
         const int kt_known = std::min(h->KT, 4);   // (KT = 8 exists only for the matrix-core update sweep)
-        a.gen_div = h->KT / kt_known;
+        a.gen_div = h->KT * h->sets / kt_known;
         HIPCHK(h, h->launch(h->LMAXv, kt_known, 0, h->Kp / (h->SG * kt_known), h->stream, &a));
     }
     return ev_mark(h, which_ev, true);
@@ -1502,7 +1510,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     {   // update kernel variant: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (kr_launch_np); N <= 64 only
         int kind = 1;
         if (h->NP <= 64) kind |= ((h->poll_delay >= 0) ? 16 : 0) | (calib_steps ? 32 : 0) | (h->herm ? 64 : 0);
-        if (h->mfma_sweep) HIPCHK(h, kr_launch_mf64(h->LMAXv, h->KT / 2, kind, h->P, h->stream, &a));
+        if (h->mfma_sweep) HIPCHK(h, kr_launch_mf64(h->LMAXv, (h->KT / 2) | (h->sets > 1 ? h->sets << 8 : 0), kind, h->P, h->stream, &a));
         else {
             a.wg_stride = (h->NP <= 64) ? h->wg_stride : 1;
             HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P * a.wg_stride, h->stream, &a));
@@ -1528,7 +1536,7 @@ static int calibrate_exchange(kr_handle *h) {
     // KROTOV_HIP_CALIBRATE_CACHE=0 measures every time.
     static std::mutex cal_mtx;
     static std::vector<std::pair<std::vector<int>, int>> cal_cache;
-    const std::vector<int> key = {h->device, h->NP, h->LMAXv, h->KT, h->P, h->herm ? 1 : 0, h->mfma_sweep ? 1 : 0, h->cfg.L, h->cfg.N};
+    const std::vector<int> key = {h->device, h->NP, h->LMAXv, h->KT, h->P, h->herm ? 1 : 0, h->mfma_sweep ? 1 : 0, h->cfg.L, h->cfg.N, h->sets, h->wg_stride};
     const bool use_cache = env_int("KROTOV_HIP_CALIBRATE_CACHE", 1) != 0;
     if (use_cache) {
         std::lock_guard<std::mutex> g(cal_mtx);

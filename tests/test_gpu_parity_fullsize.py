@@ -110,6 +110,18 @@ def test_c4_shapes_hundred_steps_vs_oracle(oracle_c, K, kt):
     _iteration_vs_oracle(p, fw, it, sample_k=(0, K // 2 + 1, K - 1), sample_n=(0, 60, 120), expect={"NP": 64, "KT": kt})
 
 
+@pytest.mark.parametrize("K,per_wg,NT", [(2048, 8, 120), (4096, 16, 60), (1500, 8, 100)])
+def test_more_than_four_trajectories_per_cu_stay_on_the_persistent_kernel(oracle_c, K, per_wg, NT):
+    """Round 3: K > 1024 at N = 64 used to fall to the generic multi-pass kernels (a 4x cliff).  The matrix-core update sweep now
+    time-multiplexes 2 or 4 sets of two tiles per workgroup within a step (partial sums accumulated over the sets before the ONE
+    exchange): K = 2048 / 4096 (and an uneven 1500) against the C oracle, N_T >= 60."""
+    p = wl.dense_problem(64, NT, K, 2, 64001, 0.05, 0.05)
+    fw, it = _c_oracle(oracle_c)
+    info = _iteration_vs_oracle(p, fw, it, sample_k=(0, 5, K // 2 + 3, K - 1), sample_n=(0, NT // 2, NT),
+                                expect={"NP": 64, "KT": 4, "traj_per_wg": per_wg, "matrix_core_sweep": 1, "generic_update": 0, "generic_known": 0})
+    assert info["workgroups"] <= 256
+
+
 def test_rowsplit_c5_liouvillian_across_refresh_boundaries():
     """C5's operators and ensemble (N=256 non-Hermitian Liouvillian, K=64: R=4 workgroups per trajectory on one XCD) over
     N_T=104 > 3 * KR_RS_REFRESH steps against the SciPy twin: known-pulse sweeps (forward, true-adjoint backward) and the
@@ -130,14 +142,15 @@ def test_rowsplit_hermitian_n100_substeps_across_refresh_boundaries(oracle_c):
     assert info["rowsplit_R"] > 1
 
 
-@pytest.mark.parametrize("shape", ["C3", "D:64,1000,512,2", "D:64,1000,128,2", "D:16,1000,300,1"])
+@pytest.mark.parametrize("shape", ["C3", "D:64,1000,512,2", "D:64,1000,128,2", "D:16,1000,300,1", "D:64,300,2048,2", "D:16,500,32,1"])
 def test_soak_many_iterations_reproducible(shape):
     """The per-step exchange validates a slot with ONE bit (kr_device.h) and every workgroup forms the pulse update for itself: a
     stale or torn slot would not raise an error, it would change a sum on SOME workgroups -- timing-dependent, so two runs would
     differ.  25 chained iterations (25 000 exchanges per run, every kernel family of the register-resident sweeps) on two
     independent engines must give bitwise identical pulses and final states, the norms of all trajectories stay 1 (a workgroup
     that propagated under a different pulse would not be caught by that, but a corrupted state would), and J_T falls
-    monotonically."""
+    monotonically.  (Round 3 adds K = 2048: several sets per workgroup, psi / chi arrays updated in place; and C2's shape: the
+    one-XCD placement with the exchange in that XCD's L2.)"""
     p = wl.config(shape)
     K, N = p["psi0"].shape
     lam = np.full(len(p["lam"]), 0.05)

@@ -48,9 +48,10 @@ def test_state_dimension_edges(oracle_c, N):
     _check(oracle_c, p)
 
 
-@pytest.mark.parametrize("K", [1, 2, 255, 256, 257, 300, 511, 512, 513, 768, 1023, 1025, 1500])
+@pytest.mark.parametrize("K", [1, 2, 255, 256, 257, 300, 511, 512, 513, 768, 1023, 1025, 1500, 2047, 2048, 2049, 4096, 4097])
 def test_trajectory_count_edges(oracle_c, K):
-    """Either side of one trajectory per CU, of the matrix-core tiles (256 x 2, 256 x 4) and past them (generic kernels)."""
+    """Either side of one trajectory per CU, of the matrix-core tiles (256 x 2, 256 x 4), of several sets per workgroup
+    (256 x 8, 256 x 16) and past them (generic kernels)."""
     p = wl.dense_problem(64, 3, K, 2, 1900 + K, 0.05, 2.0)
     _check(oracle_c, p)
 
