@@ -48,6 +48,7 @@ struct kr_handle {
     kr_launch_fn launch = nullptr;
     // row-split mode (64 < N <= 256): R workgroups of 512 threads share one trajectory (kr_device_rowsplit.h)
     bool rowsplit = false;
+    bool rs_pair = false;      // row-split PAIR mode (kr_device_rowsplit2.h): R workgroups share two trajectories and interleave them
     int R = 1, NR = 0;
     kr_launch_fn launch_rs = nullptr;
     unsigned long long *gmail_d = nullptr;
@@ -475,6 +476,16 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             h->rowsplit = true;
             if (c.L == 1 && env_int("KROTOV_HIP_RS_LMAX1", 1) != 0) h->LMAXv = 1;   // row-split kernels have an instantiation for ONE control (C5): fewer
                                                                                  // accumulators and chunk registers in the streaming passes
+            // PAIR mode: when one trajectory per group would leave 64 rows per workgroup (the H(eps) block then fills the
+            // registers, half of it in LDS, the control block is re-streamed every step and the group idles during every
+            // all-gather), the same workgroups in groups of 2R carry TWO trajectories with 32 rows each: both blocks resident,
+            // one trajectory's all-gather behind the other's row-dot.  One control, shared generator, even K (C5's shape).
+            // KROTOV_HIP_RS_PAIR=0 keeps the single mode.
+            if (NP / R == 64 && h->LMAXv == 1 && h->G == 1 && (c.K % 2) == 0 && (long long)(c.K / 2) * (2 * R) <= maxwg &&
+                env_int("KROTOV_HIP_RS_PAIR", 1) != 0) {
+                h->rs_pair = true;
+                R *= 2;
+            }
             h->R = R;
             h->NR = NP / R;
             h->threads = 512;  // mirrors KrGeomR
@@ -483,13 +494,13 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             h->RT = h->threads;
             h->SG = 1;
             h->launch_rs = (NP == 128) ? kr_launch_rs128 : kr_launch_rs256;
-            h->KT = 1;
-            h->KTILE = 1;
-            h->P = c.K * R;
+            h->KT = h->rs_pair ? 2 : 1;
+            h->KTILE = h->KT;
+            h->P = (c.K / h->KT) * R;
             h->Kp = c.K;
             h->perm.assign(c.K, 0);
-            wg_gen.assign(c.K, 0);
-            for (int k = 0; k < c.K; ++k) { h->perm[k] = k; wg_gen[k] = tg ? tg[k] : 0; }
+            wg_gen.assign(c.K / h->KT, 0);
+            for (int k = 0; k < c.K; ++k) { h->perm[k] = k; wg_gen[k / h->KT] = tg ? tg[k] : 0; }
             h->identity_perm = true;
             return KR_OK;
         }
@@ -641,7 +652,7 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
             if (h->NP <= 64 && !h->rowsplit) kind |= (sched ? 16 : 0) | (h->herm ? 64 : 0);
             else if (sched) break;
             q.on = 1; q.blocks_per_cu = -2;
-            if (h->rowsplit) (void)h->launch_rs(h->LMAXv, h->NR, 1, h->P, nullptr, &dummy);
+            if (h->rowsplit) (void)h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 3 : 1, h->P, nullptr, &dummy);
             else if (h->mfma_sweep) (void)kr_launch_mf64(h->LMAXv, (h->KT / 2) | (h->sets > 1 ? h->sets << 8 : 0), kind, h->P, nullptr, &dummy);
             else (void)h->launch(h->LMAXv, h->KT, kind, h->P, nullptr, &dummy);
             q.on = 0;
@@ -967,7 +978,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         // vector mailboxes [K][2][NP][4] + one word per workgroup (XCD ids, see kr_rowsplit_sweep); ordinary cached
         // memory: the XCD-local path of the all-gather lives on L2 hits
         h->gmail_words = (size_t)cfg->K * 2 * NP * 4 + (size_t)h->P;
-        h->xcd_group = (cfg->K % 8 == 0) && env_int("KROTOV_HIP_XCD_GROUP", 1) != 0;
+        h->xcd_group = ((cfg->K / h->KT) % 8 == 0) && env_int("KROTOV_HIP_XCD_GROUP", 1) != 0;   // (tiles % 8: pairs in pair mode)
         CHK(dalloc(&h->gmail_d, h->gmail_words));
         CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
     }
@@ -1034,7 +1045,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     {   // kr_plan_description(): which kernels carry this problem, and why if not the persistent ones
         char buf[640];
         const char *upd = h->gen_update ? "generic per-step kernels (kr_gen_partial/reduce/form/apply)"
-                        : h->rowsplit ? "kr_rowsplit_sweep" : h->mfma_sweep ? "kr_mf_update (matrix cores)"
+                        : h->rowsplit ? (h->rs_pair ? "kr_rowsplit_pair_sweep (two interleaved trajectories per group)" : "kr_rowsplit_sweep") : h->mfma_sweep ? "kr_mf_update (matrix cores)"
                         : h->NP > 64 ? "kr_stream_update" : "kr_sweep_update";
         const char *known = h->gen_known ? "kr_gen_known" : h->rowsplit ? "kr_rowsplit_sweep" : h->precomp ? "kr_expm + kr_sweep_apply" : "kr_sweep_known";
         static const char *const exn[] = {"auto", "mailbox", "rccl", "callback"};
@@ -1417,7 +1428,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     } else if (h->rowsplit) {
         rc = rowsplit_prelaunch(h, a);
         if (rc) return rc;
-        HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 0, h->P, h->stream, &a));
+        HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 2 : 0, h->P, h->stream, &a));
     } else if (h->precomp) {
         // all N_T step propagators in parallel, then one matvec round per step.  N = 64: both on the matrix cores
         // (kr_expm_mfma64 writes the propagators as MFMA A operands, kr_mf_apply_sweep applies them, two trajectories per
@@ -1505,7 +1516,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     if (h->rowsplit) {
         rc = rowsplit_prelaunch(h, a);
         if (rc) return rc;
-        HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 1, h->P, h->stream, &a));
+        HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 3 : 1, h->P, h->stream, &a));
     } else
     {   // update kernel variant: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (kr_launch_np); N <= 64 only
         int kind = 1;

@@ -67,7 +67,9 @@ def test_beyond_the_capacity_of_the_persistent_kernels(oracle_c):
     info = _check(oracle_c, wl.dense_problem(9, 10, 5, 6, 312, 0.1, 1.0))           # six controls
     assert info["generic_update"] == 1
     info = _check(oracle_c, wl.dense_problem(64, 3, 1100, 2, 313, 0.05, 5.0), check_storage=False)   # K = 1100 at N = 64
-    assert info["generic_update"] == 1 and info["K_padded"] >= 1100
+    assert info["generic_update"] == 0 and info["traj_per_wg"] == 8      # round 3: two tile sets per workgroup, still persistent
+    info = _check(oracle_c, wl.dense_problem(64, 3, 4200, 2, 314, 0.05, 5.0), check_storage=False)   # past 16 trajectories per CU
+    assert info["generic_update"] == 1 and info["K_padded"] >= 4200
 
 
 def test_generic_with_generators_and_masks(oracle_c, monkeypatch):

@@ -515,7 +515,33 @@ def test_c4_and_c5_shapes_short_grid(oracle_c):
     assert info["KT"] == 4 and info["workgroups"] == 256
     p = wl.liouvillian_problem(n_levels=16, NT=5, K=64, seed=256001)
     info = _run_case(oracle_c, p, check_storage=False)
-    assert info["rowsplit_R"] == 4 and info["workgroups"] == 256
+    assert info["rowsplit_R"] == 8 and info["KT"] == 2 and info["workgroups"] == 256     # round 3: pair mode (two trajectories per group of 8)
+
+
+@pytest.mark.parametrize("case", ["liouvillian", "hermitian_substeps", "n130"])
+def test_rowsplit_pair_mode_agrees_with_single_mode_and_oracle(oracle_c, monkeypatch, case):
+    """Row-split PAIR mode (kr_device_rowsplit2.h, round 3): groups of 2R workgroups interleave TWO trajectories (one's all-gather
+    behind the other's row-dot, H(eps) and the control block resident) where the single mode would leave 64 rows per workgroup.
+    Same arithmetic per trajectory, so the two modes must agree far inside the parity tolerances -- known-pulse sweeps (forward,
+    true-adjoint backward) and the update sweep, across rebuilds of the H(eps) block (N_T > 32), with sub-stepping, with a state
+    dimension that does not fill the padded size -- and pair mode must meet the oracle at them."""
+    if case == "liouvillian":
+        p = wl.liouvillian_problem(n_levels=16, NT=40, K=64, seed=256001, lam=0.05)
+    elif case == "hermitian_substeps":
+        p = wl.dense_problem(200, 36, 48, 1, 4200, 0.05, 0.5)
+        p["H0"] = p["H0"] * 50.0          # ||H dt|| ~ 2.5: every step is sub-stepped
+    else:
+        p = wl.dense_problem(130, 35, 40, 1, 193, 0.02, 0.2)
+    res = {}
+    for mode in ["0", "1"]:
+        monkeypatch.setenv("KROTOV_HIP_RS_PAIR", mode)
+        res[mode], info = _iterate(p)
+        assert info["rowsplit_R"] == (8 if mode == "1" else 4) and info["KT"] == (2 if mode == "1" else 1), info
+    assert _rel(res["1"][0], res["0"][0]) < 1e-12
+    assert np.max(np.abs(res["1"][2] - res["0"][2])) < 1e-12 * max(1.0, np.max(np.abs(res["0"][2])))
+    monkeypatch.setenv("KROTOV_HIP_RS_PAIR", "1")
+    if case != "liouvillian":     # (the C oracle; the Liouvillian against the SciPy twin is test_gpu_parity_fullsize.py's)
+        _run_case(oracle_c, p, check_storage=False)
 
 
 def test_full_size_properties_c5():

@@ -123,13 +123,13 @@ def test_more_than_four_trajectories_per_cu_stay_on_the_persistent_kernel(oracle
 
 
 def test_rowsplit_c5_liouvillian_across_refresh_boundaries():
-    """C5's operators and ensemble (N=256 non-Hermitian Liouvillian, K=64: R=4 workgroups per trajectory on one XCD) over
+    """C5's operators and ensemble (N=256 non-Hermitian Liouvillian, K=64: groups of R=8 workgroups carrying two trajectories each, one XCD) over
     N_T=104 > 3 * KR_RS_REFRESH steps against the SciPy twin: known-pulse sweeps (forward, true-adjoint backward) and the
     update sweep (incremental H(eps) block + correction pass)."""
     p = wl.liouvillian_problem(n_levels=16, NT=104, K=64, seed=256001, lam=0.05)
     fw, it = _scipy_twin()
     _iteration_vs_oracle(p, fw, it, sample_k=(0, 33, 63), sample_n=(0, 31, 32, 33, 64, 104),
-                         expect={"NP": 256, "rowsplit_R": 4, "workgroups": 256})
+                         expect={"NP": 256, "rowsplit_R": 8, "KT": 2, "workgroups": 256})   # round 3: pair mode
 
 
 def test_rowsplit_hermitian_n100_substeps_across_refresh_boundaries(oracle_c):
