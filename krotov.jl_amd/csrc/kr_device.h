@@ -343,6 +343,12 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #ifndef KR_SLOT_GRANULES
 #define KR_SLOT_GRANULES (LMAX)
 #endif
+// One-XCD placement (P <= 32 workgroups exchanging through ONE L2): every slot on a 128-byte line of its own.  Packed, the 8 slots of
+// C2 share one line, and that line's stores and polling loads serialise in the L2 (a poll pass took 600 ns with every slot present;
+// update sweep 3.67 -> 3.57 us per step with one slot per line).
+#ifndef KR_SLOT_GRANULES_LOCAL
+#define KR_SLOT_GRANULES_LOCAL 16
+#endif
 // One replica of the mailbox per XCD: every workgroup stores its slot into all 8 replicas (one store instruction, 8 x L active
 // lanes), the polling wave reads the replica of the XCD it runs on (HW_REG_XCC_ID) -- 32 pollers per 4 KB of slots instead of 256.
 // A poll pass with every slot present took 0.84 us at C3 (tools/exchange_arrivals.py; 2-4 x the idle load latency: 256 CUs pull
@@ -428,8 +434,10 @@ template <> struct KrPollLsb<4> {   // slot = two 16-byte words {d0, d1}, {d2, d
             asm volatile(KR_PLS(0, 2, 3, 0) KR_PLS(1, 2, 3, 16) "s_waitcnt vmcnt(0)" : "=&v"(g[0][0]), "=&v"(g[0][1]) : "v"(voff), "s"(sbase) : "memory");
     }
 };
+// sgran: 8-byte words between two slots (KR_SLOT_GRANULES: packed; KR_SLOT_GRANULES_LOCAL: one slot per 128-byte line, P <= 64 only)
 template <int LMAX>
-__device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par, const unsigned phase, const int lane, double (&tot)[LMAX]) {
+__device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par, const unsigned phase, const int lane, double (&tot)[LMAX],
+                                             const unsigned sgran = KR_SLOT_GRANULES) {
     static_assert(LMAX == 2 || LMAX == 4, "slot = LMAX doubles in 16-byte words");
     static_assert(LMAX <= 4, "publishing lanes: 4 per replica");
     constexpr int WORDS = KrPollLsb<LMAX>::WORDS;
@@ -439,9 +447,9 @@ __device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par
     for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
     for (int q0 = 0; q0 < P; q0 += 64 * KR_POLL_CHUNKS) {
         const int left = P - q0, nch = (left + 63) >> 6;   // wave-uniform
-        const unsigned long long *sbase = kr_uniform_ptr(a.mail + ((size_t)par * KR_MAIL_REPLICAS + kr_xcc_id()) * KR_MAIL_RSTRIDE + (size_t)q0 * KR_SLOT_GRANULES);
+        const unsigned long long *sbase = kr_uniform_ptr(a.mail + ((size_t)par * KR_MAIL_REPLICAS + kr_xcc_id()) * KR_MAIL_RSTRIDE + (size_t)q0 * sgran);
         kr_v4u g[KR_POLL_CHUNKS][WORDS];
-        KrPollLsb<LMAX>::pass(sbase, (unsigned)lane * (8u * LMAX), nch, g);
+        KrPollLsb<LMAX>::pass(sbase, (unsigned)lane * (8u * sgran), nch, g);
 #pragma unroll
         for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
             if (c < nch) {
@@ -524,10 +532,11 @@ struct KrMidPoll {
 // One wave gathers all P slots of buffer `par` until every slot carries `phase`; tot = sum over the slots, same order as in
 // kr_exchange.  Bounded; false = gave up (the caller's wave 0 flags it).
 template <int LMAX>
-__device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int par, const unsigned phase, const int lane, double (&tot)[LMAX]) {
+__device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int par, const unsigned phase, const int lane, double (&tot)[LMAX],
+                                                const unsigned sgran = KR_SLOT_GRANULES) {
     const unsigned long long t0 = kr_realtime();
     for (unsigned spins = 1;; ++spins) {
-        if (__all(kr_poll_pass<LMAX>(a, par, phase, lane, tot))) break;
+        if (__all(kr_poll_pass<LMAX>(a, par, phase, lane, tot, sgran))) break;
         if ((spins & 63u) == 0u) {
             const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (st != 0u || kr_realtime() - t0 > a.spin_ticks) return false;
@@ -562,6 +571,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
     // mailbox inside the GPU: buffer and phase from the step index of THIS launch (the mailbox is zeroed in front of it)
     const int lpar = n & 1;
     const unsigned phase = (((unsigned)n >> 1) & 1u) ^ 1u;
+    const unsigned sgran = xlocal ? (unsigned)KR_SLOT_GRANULES_LOCAL : (unsigned)KR_SLOT_GRANULES;   // words between slots
 
     constexpr bool EARLY = !KrIsNoWork<F>::value;   // a window exists: overlap the first poll pass with it
     __shared__ __attribute__((aligned(16))) unsigned long long spoll[EARLY ? 64 * KR_POLL_CHUNKS * LMAX : 2];
@@ -589,7 +599,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             double v = 0.0;
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) if (l == (lane & 3)) v = tot1[l];
-            const unsigned long long *dst = a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + (lane >> 2)) * KR_MAIL_RSTRIDE + (size_t)wg * KR_SLOT_GRANULES + (lane & 3);
+            const unsigned long long *dst = a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + (lane >> 2)) * KR_MAIL_RSTRIDE + (size_t)wg * sgran + (lane & 3);
             const unsigned long long val = kr_slot_bits(v, phase);
             if (xlocal) asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(dst), "v"(val) : "memory");   // stays in this XCD's L2
             else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
@@ -604,7 +614,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
         double tf[LMAX];
         const int W = a.world;
-        if (kr_gather_slots<LMAX>(a, lpar, phase, lane, tf) && lane < 2 * L * W) {
+        if (kr_gather_slots<LMAX>(a, lpar, phase, lane, tf, sgran) && lane < 2 * L * W) {
             const int r = lane / (2 * L), g = lane % (2 * L), l = g >> 1;
             double v = 0.0;
 #pragma unroll
@@ -632,7 +642,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         if (!(P == 1 && a.world == 1)) {
             // 2. publish this workgroup's partial
             if (SCHED == 0 && lane < 4 * KR_MAIL_REPLICAS && (lane & 3) < L) {   // lane = 4 * replica + l
-                kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + (lane >> 2)) * KR_MAIL_RSTRIDE + (size_t)wg * KR_SLOT_GRANULES);
+                kr_gu64 *slot = (kr_gu64 *)(a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + (lane >> 2)) * KR_MAIL_RSTRIDE + (size_t)wg * sgran);
                 double v = 0.0;
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) if (l == (lane & 3)) v = tot[l];
@@ -672,7 +682,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             const unsigned long long t0 = kr_realtime();
             unsigned spins = 0;
             for (; a.world == 1 && !done_early;) {
-                const bool ok = kr_poll_pass<LMAX>(a, lpar, phase, lane, tot);
+                const bool ok = kr_poll_pass<LMAX>(a, lpar, phase, lane, tot, sgran);
                 if (__all(ok)) break;
                 if ((++spins & 63u) == 0u) {
                     const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -794,27 +804,36 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     const double my_thr = kr_load_my_thr(a);
     const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[wg] : 0);
     // Did the placement work?  Every workgroup posts its XCC id behind the mailbox (zeroed in front of the launch), wave 0 reads
-    // all P entries: local iff they all carry this workgroup's id.  A workgroup that gives up waiting stays on the
-    // placement-independent path; mixed conclusions are harmless (a write-through store also updates this XCD's L2, and an
-    // sc0 store is visible to every sc1 load issued on the same XCD).
+    // all P entries: local iff they all carry this workgroup's id.  Every workgroup reads the SAME complete table, so all of them
+    // reach the same conclusion (they must: the local path uses one replica and one slot per 128-byte line); a workgroup that never
+    // sees the table complete aborts the sweep like any other bounded spin (the launch's workgroups are not co-resident).
     bool xlocal = false;
-    if (wstride > 1 && a.P <= 64) {
+    if (wstride > 1 && a.P <= 32) {
         __shared__ int sxl;
         if (wave == 0) {
             kr_gu64 *xtab = (kr_gu64 *)(a.mail + KR_MAIL_XTAB_OFF);
             const unsigned xcc = kr_xcc_id();
             if (lane == 0) __hip_atomic_store(xtab + wg, (1ull << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = kr_realtime();
-            bool same = false;
+            bool same = false, dead = false;
             for (;;) {
                 const unsigned long long v = __hip_atomic_load(xtab + min(lane, a.P - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all((v >> 32) != 0ull)) { same = __all((unsigned)(v & 15ull) == xcc); break; }
-                if (kr_realtime() - t0 > a.spin_ticks / 64) break;
+                if (kr_realtime() - t0 > a.spin_ticks) {
+                    if (lane == 0) {
+                        __hip_atomic_store((kr_gu32 *)a.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((kr_gu32 *)a.status + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((kr_gu32 *)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    dead = true;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (lane == 0) sxl = same ? 1 : 0;
+            if (lane == 0) sxl = dead ? -1 : (same ? 1 : 0);
         }
         __syncthreads();
+        if (sxl < 0) return;
         xlocal = (sxl != 0);
     }
     const int rowid = tid / JQ;  // 0..63
