@@ -12,6 +12,10 @@
 //     nothing is streamed per step (the drift block is read only when H(eps) is rebuilt, every KR_RS_REFRESH steps), and the
 //     H(eps) block serves both trajectories;
 //   * the LDS holds no part of the block any more (the row-dot reads x only: 16 instead of 48 ds_read_b128 per thread and round).
+// Column map (differs from the single mode): thread (il, jq) holds the STRIDED columns j = jj * JQ + jq, so the JQ lanes of a row read JQ
+// consecutive elements of x per instruction -- conflict-free without padding -- and the state vectors live in LDS as plain arrays x[e].
+// That lets the early collect pass (below) land by LDS-DMA straight in the destination vector (1 KB = 64 consecutive elements per
+// instruction), with nothing to copy afterwards.  The host packs the blocks accordingly (pack_generator_rowsplit, strided).
 // One control only (LMAX = 1: with two controls the three blocks do not fit the registers; those problems keep the single mode).
 //
 // Reference semantics: exactly kr_rowsplit_sweep's, i.e. /root/reference/src/optimize.jl:247-265, 303-317 (known-pulse sweeps,
@@ -41,7 +45,7 @@ __device__ __forceinline__ void kr_pair_deposit(KrPairBox &box, const int rb, co
     const unsigned phase = (((box.counter - 1u) >> 1) & 1u) ^ 1u;
     if (owner) {
         const int e = rb * NR + il;
-        dst[e + e / JS] = make_double2(__longlong_as_double((long long)kr_slot_bits(vr, phase)), __longlong_as_double((long long)kr_slot_bits(vi, phase)));
+        dst[e] = make_double2(__longlong_as_double((long long)kr_slot_bits(vr, phase)), __longlong_as_double((long long)kr_slot_bits(vi, phase)));
     }
 }
 template <int NP, int NR, int JS>
@@ -51,7 +55,7 @@ __device__ __forceinline__ void kr_pair_publish(const KrPairBox &box, const int 
         const int par = box.counter & 1;
         const unsigned long long *mb = box.base + (size_t)par * NP * 4;
         const int e = rb * NR + (tid & 63);
-        const double2 v = dst[e + e / JS];
+        const double2 v = dst[e];
         const unsigned long long br = (unsigned long long)__double_as_longlong(v.x), bi = (unsigned long long)__double_as_longlong(v.y);
         kr_v4u w;
         w.x = (unsigned)br; w.y = (unsigned)(br >> 32); w.z = (unsigned)bi; w.w = (unsigned)(bi >> 32);
@@ -108,7 +112,7 @@ __device__ __forceinline__ bool kr_pair_collect(const KrSweepArgs &a, const KrPa
             if (lane + 64 * c < NP - NR) {
                 const double re = __longlong_as_double((long long)(((unsigned long long)g[c].y << 32) | g[c].x));
                 const double im = __longlong_as_double((long long)(((unsigned long long)g[c].w << 32) | g[c].z));
-                dst[el[c] + el[c] / JS] = make_double2(re, im);
+                dst[el[c]] = make_double2(re, im);
             }
         }
     }
@@ -120,48 +124,37 @@ __device__ __forceinline__ bool kr_pair_collect(const KrSweepArgs &a, const KrPa
 // no result registers live across the rest of the row-dot; 1 KB per instruction, scalar base + one lane offset, M0 = LDS address)
 // -- and only CHECKED in the phase; elements that had not arrived fall back to the register polling of kr_pair_collect.
 template <int NP, int NR>
-__device__ __forceinline__ void kr_pair_collect_issue(const unsigned long long *base, const unsigned counter, const int rb, unsigned long long *stage) {
+__device__ __forceinline__ void kr_pair_collect_issue(const unsigned long long *base, const unsigned counter, const int rb, double2 *dst) {
     const int lane = threadIdx.x & 63;
     const int par = counter & 1;
-    constexpr int EC = (NP - NR + 63) / 64;
-    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void *)stage;
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void *)dst;
     const unsigned long long *sb = kr_uniform_ptr(base + (size_t)par * NP * 4);
 #pragma unroll
-    for (int c = 0; c < EC; ++c) {
-        int q = min(lane + 64 * c, NP - NR - 1);
-        if (q >= rb * NR) q += NR;
-        const unsigned voff = (unsigned)q * 16u;
-        const unsigned ld = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds + 1024u * (unsigned)c));
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(sb), "s"(ld) : "memory");
-    }
-}
-// wave 0, inside the phase: wait for the early pass, validate, move into the padded vector; false = some element had not arrived
-template <int NP, int NR, int JS>
-__device__ __forceinline__ bool kr_pair_collect_check(const KrPairBox &box, const int rb, const unsigned long long *stage, double2 *dst) {
-    const int lane = threadIdx.x & 63;
-    const unsigned phase = (((box.counter - 1u) >> 1) & 1u) ^ 1u;
-    constexpr int EC = (NP - NR + 63) / 64;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bool ok = true;
-    double2 v[EC];
-#pragma unroll
-    for (int c = 0; c < EC; ++c) {
-        v[c] = ((const double2 *)stage)[64 * c + lane];
-        const unsigned lo_r = (unsigned)__double2loint(v[c].x), lo_i = (unsigned)__double2loint(v[c].y);
-        ok = ok & ((lo_r & 1u) == phase) & ((lo_i & 1u) == phase);
-    }
-    if (!__all(ok)) return false;
-#pragma unroll
-    for (int c = 0; c < EC; ++c) {
-        if (lane + 64 * c < NP - NR) {
-            int q = lane + 64 * c;
-            if (q >= rb * NR) q += NR;
-            dst[q + q / JS] = v[c];
+    for (int c = 0; c < NP / 64; ++c) {   // piece c = elements [64 c, 64 c + 64): lane i <-> element 64 c + i, the own block's lanes stay out
+        const int e = 64 * c + lane;
+        if (e < rb * NR || e >= rb * NR + NR) {
+            const unsigned voff = (unsigned)e * 16u;
+            const unsigned ld = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds + 1024u * (unsigned)c));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(sb), "s"(ld) : "memory");
         }
     }
-    return true;
+}
+// wave 0, inside the phase: wait for the early pass and validate the vector where it landed (the own block carries the phase bit
+// too: deposit forces it); false = some element had not arrived (the register polling of kr_pair_collect then overwrites them)
+template <int NP, int NR, int JS>
+__device__ __forceinline__ bool kr_pair_collect_check(const KrPairBox &box, const int rb, const double2 *dst) {
+    const int lane = threadIdx.x & 63;
+    const unsigned phase = (((box.counter - 1u) >> 1) & 1u) ^ 1u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < NP / 64; ++c) {
+        const double2 v = dst[64 * c + lane];
+        ok = ok && (((unsigned)__double2loint(v.x) & 1u) == phase) && (((unsigned)__double2loint(v.y) & 1u) == phase);
+    }
+    return __all(ok);
 }
 
 struct KrNoMid { __device__ __forceinline__ void operator()() const {} };
@@ -170,13 +163,14 @@ struct KrPairMid {   // what the row-dot calls after its first chunk: wave 0 iss
     const unsigned long long *base;
     unsigned counter;
     int rb;
-    unsigned long long *stage;
+    double2 *dst;
     bool armed;
-    __device__ __forceinline__ void operator()() const { if (armed) kr_pair_collect_issue<NP, NR>(base, counter, rb, stage); }
+    __device__ __forceinline__ void operator()() const { if (armed) kr_pair_collect_issue<NP, NR>(base, counter, rb, dst); }
 };
 
 // row dot of the register-resident H(eps) block with the x slice (all reads of a chunk in flight first)
 // (`mid` is called once, after the first chunk: the hook for the early collect)
+// xp = &x[jq]: column jj of the thread's slice is element jj * JQ + jq of the vector
 template <int JS, int JQ, class M = KrNoMid>
 __device__ __forceinline__ void kr_pair_row_dot(const double (&Er)[JS], const double (&Ei)[JS], const double2 *__restrict__ xp,
                                                 double &sr, double &si, M mid = M()) {
@@ -187,7 +181,7 @@ __device__ __forceinline__ void kr_pair_row_dot(const double (&Er)[JS], const do
         if (j0 == (KR_PAIR_EARLY_AT ? CH : 0) || (JS == CH && j0 == 0)) mid();
         double2 x[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) x[u] = xp[j0 + u];
+        for (int u = 0; u < CH; ++u) x[u] = xp[(j0 + u) * JQ];
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const double hr = Er[j0 + u], hi = Ei[j0 + u];
@@ -206,7 +200,7 @@ __device__ __forceinline__ void kr_pair_row_dot(const double (&Er)[JS], const do
 template <int NP, int NR, bool UPDATE>
 __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepArgs a) {
     using G = KrGeomR<NP, NR, 1>;
-    constexpr int JS = G::JS, JQ = G::JQ, R = G::R, NPP = G::NPP, T = G::THREADS, KP = 2;
+    constexpr int JS = G::JS, JQ = G::JQ, R = G::R, T = G::THREADS, KP = 2;
     static_assert(G::JSL == 0 && JS <= 16, "pair mode keeps the H(eps) block in registers: NR <= 32");
     // the control block H_1: columns [0, JSH) of the thread's slice in registers, [JSH, JS) in LDS (thread-major, conflict-free).
     // It is touched three times per step (phase-A product, two H(eps) updates), not in the rounds: with all of it in registers
@@ -215,13 +209,12 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
     __shared__ __attribute__((aligned(16))) double2 sH1[(JS > JSH) ? (JS - JSH) * T : 1];
 #define KR_H1R(jj) (((jj) < JSH) ? H1r[(jj) < JSH ? (jj) : 0] : sH1[((jj) < JSH ? 0 : (jj) - JSH) * T + tid].x)
 #define KR_H1I(jj) (((jj) < JSH) ? H1i[(jj) < JSH ? (jj) : 0] : sH1[((jj) < JSH ? 0 : (jj) - JSH) * T + tid].y)
-    __shared__ __attribute__((aligned(16))) double2 sx[KP][2][NPP];   // full state vectors psi (or chi) of both trajectories, by step parity
-    __shared__ __attribute__((aligned(16))) double2 sy[KP][2][NPP];   // Horner vectors, ping-pong
+    __shared__ __attribute__((aligned(16))) double2 sx[KP][2][NP];   // full state vectors psi (or chi) of both trajectories, by step parity (plain: x[e])
+    __shared__ __attribute__((aligned(16))) double2 sy[KP][2][NP];   // Horner vectors, ping-pong
     __shared__ double spart[2 * NR];
     __shared__ double stot[2 + 1];
     __shared__ int sflag[2];
     __shared__ int salive;
-    __shared__ __attribute__((aligned(16))) unsigned long long sstage[((NP - NR + 63) / 64) * 128];   // landing zone of the early collect pass
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = a.P / R;   // pairs
@@ -233,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
     const double my_thr = kr_load_my_thr(a);
     const KrGen<1> gx = kr_gen_ctx<1>(a, a.wg_gen ? a.wg_gen[tile] : 0);
-    const int xoff = jq * (JS + 1);
+    const int xoff = jq;   // strided column map: column jj of this thread <-> element jj * JQ + jq
     const int N = a.N, NT = a.NT;
     const size_t slab = (size_t)a.Kp * N;
     size_t kbase[KP];
@@ -278,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
         for (int e = tid; e < NP; e += T) {
             double2 v = make_double2(0.0, 0.0);
             if (e < N) v = a.init[kbase[q] + e];
-            sx[q][0][e + e / JS] = v;
+            sx[q][0][e] = v;
         }
         pr[q] = 0.0; pim[q] = 0.0; cr[q] = 0.0; ci[q] = 0.0;
         if (row_ok) {
@@ -306,29 +299,39 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
 
     const bool stamp = (a.debug != nullptr) && (wg == 0);
     unsigned long long tS = 0, tD = 0, tG = 0, tX = 0, t_prev = 0, nG = 0;
+    unsigned long long prA = 0, prB = 0, prC = 0; (void)prA; (void)prB; (void)prC;
     if (stamp) t_prev = __builtin_amdgcn_s_memtime();
 #define KR_STAMP(acc) if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - t_prev; t_prev = t_; }
     // One interleaving phase: deposit trajectory q's new element (vr, vi) into dst, then -- between ONE pair of barriers -- wave 1
     // publishes q's block while wave 0 collects the OTHER trajectory's vector `odst`, published one phase earlier (its latency was
     // covered by q's row-dot).  `ocollect` false: nothing is pending for the other trajectory (first phase of a step).
+#ifdef KR_PAIR_PROBE
+#define KR_PROBE(acc) if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tp_; tp_ = t_; }
+#else
+#define KR_PROBE(acc)
+#endif
 #define KR_PAIR_PHASE(q_, vr_, vi_, dst_, ocollect_, odst_, early_)                                                      \
     {                                                                                                                    \
+        unsigned long long tp_ = stamp ? __builtin_amdgcn_s_memtime() : 0; (void)tp_;                                    \
         kr_pair_deposit<NP, NR, JS>(box[q_], rb, owner, il, vr_, vi_, dst_);                                             \
         __syncthreads();                                                                                                 \
+        KR_PROBE(prA)                                                                                                    \
         kr_pair_publish<NP, NR, JS>(box[q_], rb, dst_);                                                                  \
         if ((ocollect_) && wave == 0) {                                                                                  \
-            const bool got_ = (early_) && kr_pair_collect_check<NP, NR, JS>(box[1 - (q_)], rb, sstage, odst_);           \
+            if (early_) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                             \
+            KR_PROBE(prB)                                                                                                \
+            const bool got_ = (early_) && kr_pair_collect_check<NP, NR, JS>(box[1 - (q_)], rb, odst_);                   \
+            KR_PROBE(prC)                                                                                                \
             if (!got_) { if (!kr_pair_collect<NP, NR, JS>(a, box[1 - (q_)], rb, odst_, dbg_tpoll, dbg_npass) && lane == 0) salive = 0; } \
         }                                                                                                                \
         __syncthreads();                                                                                                 \
-        if (salive == 0) return;                                                                                         \
     }
+    // (a collect that gave up is noticed once per step, below: the status word makes every later spin of the sweep return at once)
     // Collect only (the last pending vector of a step): wave 0 polls, one barrier.
 #define KR_PAIR_COLLECT(q_, dst_)                                                                                        \
     {                                                                                                                    \
         if (wave == 0) { if (!kr_pair_collect<NP, NR, JS>(a, box[q_], rb, dst_, dbg_tpoll, dbg_npass) && lane == 0) salive = 0; } \
         __syncthreads();                                                                                                 \
-        if (salive == 0) return;                                                                                         \
     }
 
     double ecur = 0.0;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
                     for (int j0 = 0; j0 < JS; j0 += CH) {
                         double2 x[CH];
 #pragma unroll
-                        for (int u = 0; u < CH; ++u) x[u] = xp[j0 + u];
+                        for (int u = 0; u < CH; ++u) x[u] = xp[(j0 + u) * JQ];
 #pragma unroll
                         for (int u = 0; u < CH; ++u) {
                             const double er = Er[j0 + u], ei = Ei[j0 + u], hr = KR_H1R(j0 + u), hi = KR_H1I(j0 + u);
@@ -446,7 +449,8 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
                     // the other trajectory's pending vector (q = 0: trajectory 1's source of this round, if pending; q = 1: what
                     // trajectory 0 has just published): its poll pass is issued from inside this row-dot
                     const bool early = KR_PAIR_EARLY && (q == 1 || pend1);
-                    const KrPairMid<NP, NR> mid{box[1 - q].base, box[1 - q].counter, rb, sstage, early && wave == 0};
+                    double2 *pending = (q == 0) ? src[1] : (last ? sx[0][cur ^ 1] : sy[0][w]);   // where the other trajectory's vector lands
+                    const KrPairMid<NP, NR> mid{box[1 - q].base, box[1 - q].counter, rb, pending, early && wave == 0};
                     kr_pair_row_dot<JS, JQ>(Er, Ei, src[q] + xoff, sr, si, mid);
                     yr[q] = fma(f, si, x0r[q]);
                     yi[q] = fma(-f, sr, x0i[q]);
@@ -480,6 +484,7 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
 #pragma unroll
             for (int q = 0; q < KP; ++q) { pr[q] = yr[q]; pim[q] = yi[q]; }
             cur ^= 1;
+            if (salive == 0) return;   // (uniform: read behind the last collect's barrier; set when a bounded spin gave up)
         }
         if (a.store && owner && row_ok) {
             const int slot = (a.dir > 0) ? (n + 1) : n;
@@ -487,7 +492,11 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
             for (int q = 0; q < KP; ++q) a.store[(size_t)slot * slab + kbase[q] + row] = make_double2(pr[q], pim[q]);
         }
     }
-    if (stamp && tid == 0) { a.debug[0] = tS; a.debug[1] = tD; a.debug[2] = tG; a.debug[3] = tX; a.debug[7] = nG; a.debug[5] = dbg_tpoll; a.debug[6] = dbg_npass; }
+    if (stamp && tid == 0) { a.debug[0] = tS; a.debug[1] = tD; a.debug[2] = tG; a.debug[3] = tX; a.debug[7] = nG; a.debug[5] = dbg_tpoll; a.debug[6] = dbg_npass;
+#ifdef KR_PAIR_PROBE
+        a.debug[4] = prA; a.debug[5] = prB; a.debug[6] = prC;
+#endif
+    }
 #undef KR_STAMP
 #undef KR_PAIR_PHASE
 #undef KR_PAIR_COLLECT

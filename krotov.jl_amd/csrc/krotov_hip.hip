@@ -233,15 +233,16 @@ static void pack_generator(int N, int NP, int JQ, const zc *M, bool adj, double2
             }
 }
 
-// Row-split pack: out[((jj)*R + rb)*T + il*JQ + jq] = M[rb*NR + il][jq*JS + jj]  (one matrix; zero outside N)
-static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj, double2 *out) {
+// Row-split pack: out[((jj)*R + rb)*T + il*JQ + jq] = M[rb*NR + il][column of (jq, jj)]  (one matrix; zero outside N).
+// Column map: contiguous segments jq*JS + jj (single mode, padded LDS vectors) or strided jj*JQ + jq (pair mode, plain vectors)
+static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj, double2 *out, bool strided) {
     const int T = 512;
     const int R = NP / NR, JQ = T / NR, JS = NP / JQ;
     for (int jj = 0; jj < JS; ++jj)
         for (int rb = 0; rb < R; ++rb)
             for (int il = 0; il < NR; ++il)
                 for (int jq = 0; jq < JQ; ++jq) {
-                    const int i = rb * NR + il, j = jq * JS + jj;
+                    const int i = rb * NR + il, j = strided ? (jj * JQ + jq) : (jq * JS + jj);
                     zc v = 0;
                     if (i < N && j < N) v = adj ? std::conj(M[j + (size_t)i * N]) : M[i + (size_t)j * N];
                     out[((size_t)jj * R + rb) * T + il * JQ + jq] = make_double2(v.real(), v.imag());
@@ -888,7 +889,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
             {
                 const zc *M = (m == 0) ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn;
                 double2 *dst = pack.data() + (size_t)g * h->pack_stride + (size_t)m * NP * NP;
-                if (h->rowsplit) pack_generator_rowsplit(N, NP, h->NR, M, adj != 0, dst);
+                if (h->rowsplit) pack_generator_rowsplit(N, NP, h->NR, M, adj != 0, dst, h->rs_pair);
                 else pack_generator(N, NP, h->JQ, M, adj != 0, dst);
             }
         CHK(hipMemcpy(adj ? h->Hpack_bw : h->Hpack_fw, pack.data(), pack_elems * sizeof(double2), hipMemcpyHostToDevice));

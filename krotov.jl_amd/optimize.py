@@ -48,9 +48,13 @@ def discretize_on_midpoints(control, tlist):
     if len(c) == NT + 1:
         # exact inverse of discretize(): c[i] = (v[i-1] + v[i]) / 2  [UPSTREAM-RECALLED; the hand-over tests
         # test_tls_optimization.jl:126,160 (J_T continuity to 1e-14) only hold if the round trip is exact]
+        # [UPSTREAM-RECALLED QuantumPropagators.Controls.discretize_on_midpoints(::Vector, tlist)]: first AND last interval value
+        # pinned to the first / last point value, the interior by the recursion -- on a round trip through discretize() identical
+        # to the pure recursion (the last interval comes back exactly), on an arbitrary array it differs in the last value only
         v = np.empty(NT)
         v[0] = c[0]
-        for i in range(1, NT):
+        v[-1] = c[-1]
+        for i in range(1, NT - 1):
             v[i] = 2.0 * c[i] - v[i - 1]
         return v
     raise ValueError("control array must have length len(tlist) or len(tlist)-1")

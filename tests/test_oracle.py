@@ -135,3 +135,17 @@ def test_discretisation_round_trip():
     assert len(c) == 11 and c[0] == p[0] and c[-1] == p[-1] and c[3] == 0.5 * (p[2] + p[3])
     q = o.discretize_on_midpoints(p, tlist)
     assert q is not p and np.array_equal(q, p)  # a copy (test_pulse_optimization.jl:42)
+    # length N_T + 1: first and last interval pinned to the end points, interior by the recursion [UPSTREAM-RECALLED]:
+    # exact on a round trip through discretize() (what the hand-over tests test_tls_optimization.jl:126,160 need) ...
+    rng = np.random.default_rng(3)
+    pulse = rng.normal(size=10)
+    back = o.discretize_on_midpoints(o.discretize(pulse, tlist), tlist)
+    assert np.max(np.abs(back - pulse)) < 1e-14 and back[0] == pulse[0] and back[-1] == pulse[-1]
+    # ... and on an arbitrary array of point values the last interval takes the last point's value, not the recursion's
+    ctrl = rng.normal(size=11)
+    v = o.discretize_on_midpoints(ctrl, tlist)
+    assert v[0] == ctrl[0] and v[-1] == ctrl[-1]
+    for i in range(1, 9):
+        assert v[i] == 2.0 * ctrl[i] - v[i - 1]
+    import krotov_jl_amd as kr      # the host mirror restates the same function (the package never imports the oracle)
+    assert np.array_equal(kr.discretize_on_midpoints(ctrl, tlist), v)
