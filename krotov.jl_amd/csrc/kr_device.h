@@ -781,7 +781,9 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 // and the exchange; forming H(eps_guess), the products b = H(eps_guess) psi and a_l = H_l psi (needed for the free first
 // application) and c_l(n+1) are computed by all waves WHILE the partial sums travel (kr_exchange's `work`), i.e. phase A
 // leaves the critical path of the step.  chi(t_{n+1}) must then be in LDS one step earlier (prefetch distance 2).
-template <int NP, int LMAX, int KT, int SCHED, int CAL, int HERM>
+// XLOC = 1: the launch uses the one-XCD placement (KrSweepArgs::wg_stride > 1, P <= 32 workgroups).  A template parameter, not a
+// run-time flag: as a flag it cost the big grids 2 % (C3: 5.55 -> 5.65 us per step, same-box A/B) for a path they never take.
+template <int NP, int LMAX, int KT, int SCHED, int CAL, int HERM, int XLOC = 0>
 __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, KT>::THREADS / 256)) void kr_sweep_update(const KrSweepArgs a) {
     using G = KrGeom<NP, LMAX, KT>;
     constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, KTILE = G::KTILE, NPP = G::NPP, NW = G::NW;
@@ -794,8 +796,8 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     __shared__ double stot[LMAX + 1];
 
     // one-XCD placement of a small grid (KrSweepArgs::wg_stride): only every wg_stride-th block works
-    const int wstride = a.wg_stride > 1 ? a.wg_stride : 1;
-    if (wstride > 1 && (blockIdx.x % wstride) != 0) return;
+    const int wstride = (XLOC && a.wg_stride > 1) ? a.wg_stride : 1;
+    if (XLOC && wstride > 1 && (blockIdx.x % wstride) != 0) return;
     const int tid = threadIdx.x, wg = blockIdx.x / wstride, lane = tid & 63, wave = tid >> 6;
     const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
     const bool writer = (jq == 0), row_ok = (i < a.N);
@@ -808,7 +810,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     // reach the same conclusion (they must: the local path uses one replica and one slot per 128-byte line); a workgroup that never
     // sees the table complete aborts the sweep like any other bounded spin (the launch's workgroups are not co-resident).
     bool xlocal = false;
-    if (wstride > 1 && a.P <= 32) {
+    if (XLOC && wstride > 1 && a.P <= 32) {
         __shared__ int sxl;
         if (wave == 0) {
             kr_gu64 *xtab = (kr_gu64 *)(a.mail + KR_MAIL_XTAB_OFF);
@@ -1008,7 +1010,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 
         // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
         double du[LMAX];
-        if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot, window, xlocal)) return;
+        if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot, window, XLOC ? xlocal : false)) return;
 
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 
@@ -1183,6 +1185,9 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
 #define KR_CASE(LM, KTv)                                                                          \
     if (lmax == LM && kt == KTv) {                                                                \
         if (kind == 0) kr_launch_kernel((kr_sweep_known<NP, LM, KTv>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
+        else if ((kind & 15) == 1 && (kind & 128)) {  /* one-XCD placement (P <= 32: classic schedule, general variant, no calibration) */ \
+            kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 0, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
+        } \
         else if ((kind & 15) == 1) {  /* update sweep: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 */ \
             switch (kind >> 4) { \
             case 0: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 0, 0>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \

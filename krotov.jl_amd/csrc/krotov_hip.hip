@@ -566,10 +566,16 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
     }
     // Few workgroups (C2: 8): put them all on ONE XCD so that the per-step exchange stays in its L2 (KrSweepArgs::wg_stride).
     // Only when this handle has the GPU to itself (the other XCDs' blocks exit at once, but they must be dispatched) and for the
-    // vector update kernel.  KROTOV_HIP_XCD_LOCAL=0 switches it off.
+    // vector update kernel.  KROTOV_HIP_XCD_LOCAL=0 switches it off; = 2 forces it for a handle that shares its GPU (tests: several
+    // ranks on the one GPU of the build box, the shape a shard of 32 trajectories has on every GPU of an 8-GPU run).
     h->wg_stride = 1;
-    if (NP <= 64 && !h->mfma_sweep && h->P >= 2 && h->P <= 32 && maxwg == cus && env_int("KROTOV_HIP_XCD_LOCAL", 1) != 0)
-        h->wg_stride = 8;
+    {
+        const int xl = env_int("KROTOV_HIP_XCD_LOCAL", 1);
+        // (an explicitly forced kernel variant -- KROTOV_HIP_HERM = 2, KROTOV_HIP_POLL_DELAY >= 0 -- keeps the ordinary launch: the
+        //  placement kernel exists for the classic schedule of the general variant only)
+        const bool forced = env_int("KROTOV_HIP_HERM", 1) == 2 || env_int("KROTOV_HIP_POLL_DELAY", -2) >= 0;
+        if (NP <= 64 && !h->mfma_sweep && h->P >= 2 && h->P <= 32 && (maxwg == cus || xl == 2) && xl != 0 && !forced) h->wg_stride = 8;
+    }
     return KR_OK;
 }
 
@@ -603,6 +609,7 @@ static void decide_herm(kr_handle *h, const kr_config *cfg) {
     //  dot + exchange --, with two tiles its five products outlast the exchange: C4 11.74 vs 11.35 us per step)
     h->herm = (mode == 2) || (mode == 1 && (h->mfma_sweep ? h->KT == 2 : h->KT == 1) && h->P >= 64 && h->NP <= 64);
     if (h->sets > 1) h->herm = false;   // several sets per workgroup: general variant only
+    if (h->wg_stride > 1) h->herm = false;   // one-XCD placement (P <= 32): kr_sweep_update<.., XLOC = 1> is the general variant
     if (h->mfma_sweep && h->LMAXv == 4 && h->KT == 4) h->herm = false;   // that instantiation spills (212 B): general variant
     if (h->rowsplit || h->NP > 64) h->herm = false;
     for (int g = 0; g < G && h->herm; ++g) {
@@ -1524,7 +1531,8 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
         if (h->NP <= 64) kind |= ((h->poll_delay >= 0) ? 16 : 0) | (calib_steps ? 32 : 0) | (h->herm ? 64 : 0);
         if (h->mfma_sweep) HIPCHK(h, kr_launch_mf64(h->LMAXv, (h->KT / 2) | (h->sets > 1 ? h->sets << 8 : 0), kind, h->P, h->stream, &a));
         else {
-            a.wg_stride = (h->NP <= 64) ? h->wg_stride : 1;
+            a.wg_stride = (h->NP <= 64 && !calib_steps) ? h->wg_stride : 1;
+            if (a.wg_stride > 1) kind = 1 | 128;   // kr_sweep_update<.., XLOC = 1>: classic schedule, general variant
             HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P * a.wg_stride, h->stream, &a));
         }
     }

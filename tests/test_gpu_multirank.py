@@ -28,6 +28,8 @@ def _problem(which):
         return wl.dense_problem(20, 30, 256, 2, 913, 0.1, 1.0), 256
     if which == "wide":        # 64 workgroups per rank: calibrated exchange schedule + Hermitian-controls kernel variant
         return wl.dense_problem(20, 30, 256, 2, 913, 0.1, 1.0), 256
+    if which == "xcd_local":  # few workgroups per rank, all placed on ONE XCD (exchange in its L2) AND a second rank behind the xmail hop:
+        return wl.dense_problem(16, 60, 24, 2, 915, 0.1, 1.0), 24   # the shape of a 32-trajectory shard on each GPU of an 8-GPU run
     if which == "odd_nt":     # odd N_T: consecutive launches must keep alternating the mailbox buffers
         return wl.dense_problem(16, 61, 24, 2, 911, 0.1, 1.0), 24
     return wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0), 24
@@ -38,6 +40,8 @@ def _worker(rank, world, port, q, which="small"):
     max_wg = 48 if world > 2 else 64   # the ranks share ONE GPU: each takes a share of its CUs (kr_config.max_workgroups)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if which == "xcd_local":
+        os.environ["KROTOV_HIP_XCD_LOCAL"] = "2"    # force the one-XCD placement although the ranks share the GPU
     if which == "skewed" and rank == 0:
         # kr_create's calibration runs a timing-dependent number of update launches; they must not advance the tag
         # sequence the ranks share (round-1 advisor finding): here rank 0 runs none at all, rank 1 runs 24-30
@@ -51,6 +55,8 @@ def _worker(rank, world, port, q, which="small"):
         p, K = _problem(which)
         a, b = shard_range(K, rank, world)
         eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], b - a, device=0, rank=rank, world=world, K_global=K, max_workgroups=max_wg)
+        if which == "xcd_local":
+            assert "one-XCD placement 1" in eng.plan(), eng.plan()
         connect_peers(eng, dist)
         eng.set_initial_states(p["psi0"][a:b])
         psiT = eng.forward(p["eps"])
@@ -109,7 +115,7 @@ def _run_ranks(which, world):
     return got
 
 
-@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks"])
+@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks", "xcd_local"])
 def test_two_ranks_one_gpu_equals_unsharded(which):
     world = 4 if which == "four_ranks" else 2
     sys.path.insert(0, ROOT)
