@@ -480,9 +480,9 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             // PAIR mode: when one trajectory per group would leave 64 rows per workgroup (the H(eps) block then fills the
             // registers, half of it in LDS, the control block is re-streamed every step and the group idles during every
             // all-gather), the same workgroups in groups of 2R carry TWO trajectories with 32 rows each: both blocks resident,
-            // one trajectory's all-gather behind the other's row-dot.  One control, shared generator, even K (C5's shape).
-            // KROTOV_HIP_RS_PAIR=0 keeps the single mode.
-            if (NP / R == 64 && h->LMAXv == 1 && h->G == 1 && (c.K % 2) == 0 && (long long)(c.K / 2) * (2 * R) <= maxwg &&
+            // one trajectory's all-gather behind the other's row-dot.  One control, shared generator (C5's shape); an odd K is
+            // padded with one zero trajectory (it contributes nothing to any sum).  KROTOV_HIP_RS_PAIR=0 keeps the single mode.
+            if (NP / R == 64 && h->LMAXv == 1 && h->G == 1 && c.K >= 2 && (long long)((c.K + 1) / 2) * (2 * R) <= maxwg &&
                 env_int("KROTOV_HIP_RS_PAIR", 1) != 0) {
                 h->rs_pair = true;
                 R *= 2;
@@ -497,10 +497,10 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             h->launch_rs = (NP == 128) ? kr_launch_rs128 : kr_launch_rs256;
             h->KT = h->rs_pair ? 2 : 1;
             h->KTILE = h->KT;
-            h->P = (c.K / h->KT) * R;
-            h->Kp = c.K;
+            h->Kp = ((c.K + h->KT - 1) / h->KT) * h->KT;   // pair mode: padded to an even count
+            h->P = (h->Kp / h->KT) * R;
             h->perm.assign(c.K, 0);
-            wg_gen.assign(c.K / h->KT, 0);
+            wg_gen.assign(h->Kp / h->KT, 0);
             for (int k = 0; k < c.K; ++k) { h->perm[k] = k; wg_gen[k / h->KT] = tg ? tg[k] : 0; }
             h->identity_perm = true;
             return KR_OK;
@@ -985,8 +985,8 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     if (h->rowsplit) {
         // vector mailboxes [K][2][NP][4] + one word per workgroup (XCD ids, see kr_rowsplit_sweep); ordinary cached
         // memory: the XCD-local path of the all-gather lives on L2 hits
-        h->gmail_words = (size_t)cfg->K * 2 * NP * 4 + (size_t)h->P;
-        h->xcd_group = ((cfg->K / h->KT) % 8 == 0) && env_int("KROTOV_HIP_XCD_GROUP", 1) != 0;   // (tiles % 8: pairs in pair mode)
+        h->gmail_words = (size_t)h->Kp * 2 * NP * 4 + (size_t)h->P;
+        h->xcd_group = ((h->Kp / h->KT) % 8 == 0) && env_int("KROTOV_HIP_XCD_GROUP", 1) != 0;   // (tiles % 8: pairs in pair mode)
         CHK(dalloc(&h->gmail_d, h->gmail_words));
         CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
     }

@@ -518,7 +518,7 @@ def test_c4_and_c5_shapes_short_grid(oracle_c):
     assert info["rowsplit_R"] == 8 and info["KT"] == 2 and info["workgroups"] == 256     # round 3: pair mode (two trajectories per group of 8)
 
 
-@pytest.mark.parametrize("case", ["liouvillian", "hermitian_substeps", "n130"])
+@pytest.mark.parametrize("case", ["liouvillian", "hermitian_substeps", "n130", "odd_k", "np128_local", "np128"])
 def test_rowsplit_pair_mode_agrees_with_single_mode_and_oracle(oracle_c, monkeypatch, case):
     """Row-split PAIR mode (kr_device_rowsplit2.h, round 3): groups of 2R workgroups interleave TWO trajectories (one's all-gather
     behind the other's row-dot, H(eps) and the control block resident) where the single mode would leave 64 rows per workgroup.
@@ -530,13 +530,20 @@ def test_rowsplit_pair_mode_agrees_with_single_mode_and_oracle(oracle_c, monkeyp
     elif case == "hermitian_substeps":
         p = wl.dense_problem(200, 36, 48, 1, 4200, 0.05, 0.5)
         p["H0"] = p["H0"] * 50.0          # ||H dt|| ~ 2.5: every step is sub-stepped
+    elif case == "odd_k":          # 33 trajectories: the 17th pair carries one zero trajectory
+        p = wl.dense_problem(256, 34, 33, 1, 194, 0.01, 0.2)
+    elif case == "np128_local":    # 64 < N <= 128: single mode R = 2, pair mode groups of 4; 48 pairs -> one XCD per group
+        p = wl.dense_problem(100, 36, 96, 1, 195, 0.02, 0.2)
+    elif case == "np128":          # 50 pairs: placement-independent path
+        p = wl.dense_problem(128, 34, 100, 1, 196, 0.02, 0.2)
     else:
         p = wl.dense_problem(130, 35, 40, 1, 193, 0.02, 0.2)
+    r_single = 2 if case.startswith("np128") else 4
     res = {}
     for mode in ["0", "1"]:
         monkeypatch.setenv("KROTOV_HIP_RS_PAIR", mode)
         res[mode], info = _iterate(p)
-        assert info["rowsplit_R"] == (8 if mode == "1" else 4) and info["KT"] == (2 if mode == "1" else 1), info
+        assert info["rowsplit_R"] == (2 * r_single if mode == "1" else r_single) and info["KT"] == (2 if mode == "1" else 1), info
     assert _rel(res["1"][0], res["0"][0]) < 1e-12
     assert np.max(np.abs(res["1"][2] - res["0"][2])) < 1e-12 * max(1.0, np.max(np.abs(res["0"][2])))
     monkeypatch.setenv("KROTOV_HIP_RS_PAIR", "1")
