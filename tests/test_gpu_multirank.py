@@ -30,6 +30,8 @@ def _problem(which):
         return wl.dense_problem(20, 30, 256, 2, 913, 0.1, 1.0), 256
     if which == "xcd_local":  # few workgroups per rank, all placed on ONE XCD (exchange in its L2) AND a second rank behind the xmail hop:
         return wl.dense_problem(16, 60, 24, 2, 915, 0.1, 1.0), 24   # the shape of a 32-trajectory shard on each GPU of an 8-GPU run
+    if which == "tile_sets":  # N = 64, 600 trajectories per rank on 64 workgroups: four tile sets per workgroup (round 3), partial sums of all
+        return wl.dense_problem(64, 8, 1200, 2, 916, 0.05, 0.05), 1200   # sets accumulated in front of the one exchange that crosses the ranks
     if which == "odd_nt":     # odd N_T: consecutive launches must keep alternating the mailbox buffers
         return wl.dense_problem(16, 61, 24, 2, 911, 0.1, 1.0), 24
     return wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0), 24
@@ -115,7 +117,7 @@ def _run_ranks(which, world):
     return got
 
 
-@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks", "xcd_local"])
+@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks", "xcd_local", "tile_sets"])
 def test_two_ranks_one_gpu_equals_unsharded(which):
     world = 4 if which == "four_ranks" else 2
     sys.path.insert(0, ROOT)

@@ -266,3 +266,60 @@ def test_spin_bound_is_configurable():
     assert code == capi.KR_ERR_TIMEOUT, got[0]
     assert 0.25 < secs < 2.5, got[0]
     assert "exchange" in got[0][2]
+
+
+# ---- several tile sets per workgroup with per-trajectory generators and an absent control derivative ------------------
+def test_tile_sets_with_per_trajectory_generators_and_masks():
+    """K = 1500 at N = 64 with G = 3 different generators (control_derivs[k][l], /root/reference/src/workspace.jl:74) of which one
+    lacks control 1 (mu === nothing, optimize.jl:344): the workgroups carry two tile sets each and never mix generators.  Against a
+    serial restatement of optimize.jl:328-370 built on the oracle's exact step propagator."""
+    import krotov_oracle as o
+    rng = np.random.default_rng(91)
+    N, NT, L, G = 64, 6, 2, 3
+    counts = [700, 500, 300]
+    K = sum(counts)
+    tg = rng.permutation(np.repeat(np.arange(G, dtype=np.int32), counts)).astype(np.int32)
+    base = wl.dense_problem(N, NT, K, L, 920, 0.05, 0.05)
+    H0 = np.array([base["H0"] * (1.0 + 0.1 * g) + 0.05 * wl.random_hermitian(rng, N) for g in range(G)])
+    Hc = np.array([[base["Hc"][l] * (1.0 - 0.07 * g) for l in range(L)] for g in range(G)])
+    present = np.ones((G, L), np.uint8)
+    present[1, 1] = 0
+    tl, eps, S, lam, psi0, tgt = base["tlist"], base["eps"], base["S"], base["lam"], base["psi0"], base["tgt"]
+    with kr.HipEngine(H0, Hc, tl, K, traj_generator=tg, hc_present=present) as eng:
+        info = eng.info()
+        assert info["matrix_core_sweep"] == 1 and info["traj_per_wg"] == 8 and info["generic_update"] == 0, eng.plan()
+        eng.set_initial_states(psi0)
+        psiT = eng.forward(eps)
+        U = [[o.step_propagator(H0[g], Hc[g], eps[:, n], tl[n + 1] - tl[n]) for n in range(NT)] for g in range(G)]
+        psi = psi0.copy()
+        for n in range(NT):
+            for g in range(G):
+                ks = tg == g
+                psi[ks] = psi[ks] @ U[g][n].T
+        assert np.max(np.abs(psiT - psi)) < 1e-11
+        _, _, chiT = wl.chi_and_JT("ss", psi, tgt)
+        eps_new, ga, psiT1 = eng.iteration(eps, chiT, S, lam)
+        X_probe = eng.read_storage("bw", 777, 2)
+    X = np.empty((NT + 1, K, N), complex)
+    X[NT] = chiT
+    for n in range(NT - 1, -1, -1):
+        for g in range(G):
+            ks = tg == g
+            X[n, ks] = X[n + 1, ks] @ U[g][n].conj()       # chi <- U^dagger chi
+    assert np.max(np.abs(X_probe - X[2, 777])) < 1e-11
+    psi, eps_o, ga_o = psi0.copy(), eps.copy(), np.zeros(L)
+    for n in range(NT):
+        dt = tl[n + 1] - tl[n]
+        for l in range(L):
+            du = 0.0
+            for g in range(G):
+                if present[g, l]:
+                    ks = tg == g
+                    du += np.sum(np.conj(X[n, ks]) * (psi[ks] @ Hc[g, l].T)).imag
+            eps_o[l, n] = eps[l, n] + S[l, n] / lam[l] * du
+            ga_o[l] += S[l, n] / lam[l] * du * du * dt
+        for g in range(G):
+            ks = tg == g
+            psi[ks] = psi[ks] @ o.step_propagator(H0[g], Hc[g], eps_o[:, n], dt).T
+    assert np.max(np.abs(eps_o - eps)) > 1e-5
+    assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < TOL_GA and np.max(np.abs(psiT1 - psi)) < TOL_STATE
