@@ -56,6 +56,19 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void round_kernel(double *o
             }
         }
         double sr = a - b, si = c + d;
+        if (VAR == 7) {  // VAR 7 (round 3): the 4-lane part of the reduction on the matrix core -- v_mfma_f64_4x4x4 with B = ones sums lanes
+                         // l, l ^ 16, l ^ 32, l ^ 48 --, then ONE DPP stage (row_half_mirror); timing only (lane roles not modelled)
+            sr = __builtin_amdgcn_mfma_f64_4x4x4f64(sr, 1.0, 0.0, 0, 0, 0);
+            si = __builtin_amdgcn_mfma_f64_4x4x4f64(si, 1.0, 0.0, 0, 0, 0);
+            sr += dppmov<0x141>(sr); si += dppmov<0x141>(si);
+        } else if (VAR == 8) {  // VAR 8: transposed reduce -- after the first exchange a lane carries ONE of the two values
+            const bool odd = threadIdx.x & 1;
+            const double keep = odd ? si : sr, send = odd ? sr : si;
+            double v = keep + dppmov<0xB1>(send);
+            v += dppmov<0x4E>(v);
+            if (JQ == 8) v += dppmov<0x141>(v);
+            sr = v; si = dppmov<0xB1>(v);
+        } else
         if (VAR != 1) {  // VAR 1: no DPP reduction
             sr += dppmov<0xB1>(sr); si += dppmov<0xB1>(si);
             sr += dppmov<0x4E>(sr); si += dppmov<0x4E>(si);
@@ -93,6 +106,11 @@ int main() {
     (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost); \
     printf("JS=%2d JQ=%d threads=%d (NP=%2d) %-12s: %.1f cycles per round\n", JS, JQv, TH, JQv * JS, label, (double)h / iters);
     RUN2(8, 8, 512, "512-thread") RUN2(4, 16, 1024, "1024-thread") RUN2(16, 4, 256, "256-thread")
+#define RUN3(VAR, label) \
+    hipLaunchKernelGGL((round_kernel<8, VAR, 8, 512>), dim3(256), dim3(512), 0, 0, out, cyc, iters); \
+    (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost); \
+    printf("JS= 8 JQ=8 threads=512 (NP=64) %-28s: %.1f cycles per round\n", label, (double)h / iters);
+    RUN3(0, "baseline (3 DPP stages)") RUN3(1, "no reduction") RUN3(7, "MFMA 4-lane sum + 1 DPP stage") RUN3(8, "transposed reduce") RUN3(3, "raw s_barrier")
     RUN(4, 4, "FMAs, 1 LDS read") RUN(4, 5, "4 LDS reads, adds only") RUN(4, 6, "non-broadcast reads")
     return 0;
 }
