@@ -22,6 +22,9 @@
 // true adjoint for the backward one: workspace.jl:69,149-161) and :321-370 (update sweep).
 #pragma once
 #include "kr_device_rowsplit.h"
+#ifndef KR_PAIR_NOVERIFY
+#define KR_PAIR_NOVERIFY 0   // 1: TIMING EXPERIMENT ONLY -- trust the early pass without validating it (wrong results when it missed)
+#endif
 #ifndef KR_PAIR_EARLY_AT
 #define KR_PAIR_EARLY_AT 1   // where in the row-dot: 0 = in front of the first chunk of columns, 1 = behind it
 #endif
@@ -141,19 +144,22 @@ __device__ __forceinline__ void kr_pair_collect_issue(const unsigned long long *
         }
     }
 }
-// wave 0, inside the phase: wait for the early pass and validate the vector where it landed (the own block carries the phase bit
-// too: deposit forces it); false = some element had not arrived (the register polling of kr_pair_collect then overwrites them)
-template <int NP, int NR, int JS>
-__device__ __forceinline__ bool kr_pair_collect_check(const KrPairBox &box, const int rb, const double2 *dst) {
+// wave 0: the early pass is retired and the landed vector READ in front of the phase's first barrier (the LDS latency of the four
+// reads hides in the barrier), tested behind it; false = some element had not arrived (kr_pair_collect then polls them in)
+template <int NP>
+__device__ __forceinline__ void kr_pair_check_load(const double2 *dst, double2 (&v)[NP / 64]) {
     const int lane = threadIdx.x & 63;
-    const unsigned phase = (((box.counter - 1u) >> 1) & 1u) ^ 1u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < NP / 64; ++c) v[c] = dst[64 * c + lane];
+}
+template <int NP>
+__device__ __forceinline__ bool kr_pair_check_test(const KrPairBox &box, const double2 (&v)[NP / 64]) {
+    const unsigned phase = (((box.counter - 1u) >> 1) & 1u) ^ 1u;
     bool ok = true;
 #pragma unroll
-    for (int c = 0; c < NP / 64; ++c) {
-        const double2 v = dst[64 * c + lane];
-        ok = ok && (((unsigned)__double2loint(v.x) & 1u) == phase) && (((unsigned)__double2loint(v.y) & 1u) == phase);
-    }
+    for (int c = 0; c < NP / 64; ++c)
+        ok = ok && (((unsigned)__double2loint(v[c].x) & 1u) == phase) && (((unsigned)__double2loint(v[c].y) & 1u) == phase);
     return __all(ok);
 }
 
@@ -313,14 +319,18 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
 #define KR_PAIR_PHASE(q_, vr_, vi_, dst_, ocollect_, odst_, early_)                                                      \
     {                                                                                                                    \
         unsigned long long tp_ = stamp ? __builtin_amdgcn_s_memtime() : 0; (void)tp_;                                    \
+        double2 chk_[NP / 64];                                                                                           \
+        /* known-pulse sweeps: the landed vector is read IN FRONT of the barrier (16.95 -> 16.05 us per step at C5); the update   \
+           kernel has no 16 registers to keep across it (it spilled 108 B and lost what the reads had gained): it reads behind */ \
+        if (!UPDATE && (ocollect_) && (early_) && wave == 0) kr_pair_check_load<NP>(odst_, chk_);                         \
         kr_pair_deposit<NP, NR, JS>(box[q_], rb, owner, il, vr_, vi_, dst_);                                             \
         __syncthreads();                                                                                                 \
         KR_PROBE(prA)                                                                                                    \
         kr_pair_publish<NP, NR, JS>(box[q_], rb, dst_);                                                                  \
         if ((ocollect_) && wave == 0) {                                                                                  \
-            if (early_) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                             \
+            if (UPDATE && (early_)) kr_pair_check_load<NP>(odst_, chk_);                                                 \
             KR_PROBE(prB)                                                                                                \
-            const bool got_ = (early_) && kr_pair_collect_check<NP, NR, JS>(box[1 - (q_)], rb, odst_);                   \
+            const bool got_ = (early_) && (KR_PAIR_NOVERIFY || kr_pair_check_test<NP>(box[1 - (q_)], chk_));             \
             KR_PROBE(prC)                                                                                                \
             if (!got_) { if (!kr_pair_collect<NP, NR, JS>(a, box[1 - (q_)], rb, odst_, dbg_tpoll, dbg_npass) && lane == 0) salive = 0; } \
         }                                                                                                                \
