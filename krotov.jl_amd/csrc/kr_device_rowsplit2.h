@@ -22,6 +22,9 @@
 // true adjoint for the backward one: workspace.jl:69,149-161) and :321-370 (update sweep).
 #pragma once
 #include "kr_device_rowsplit.h"
+#ifndef KR_PAIR_PRE
+#define KR_PAIR_PRE 1   // wave 0 reads the landed vector's phase bits in front of the phase's first barrier (0: behind it)
+#endif
 #ifndef KR_PAIR_NOVERIFY
 #define KR_PAIR_NOVERIFY 0   // 1: TIMING EXPERIMENT ONLY -- trust the early pass without validating it (wrong results when it missed)
 #endif
@@ -146,20 +149,22 @@ __device__ __forceinline__ void kr_pair_collect_issue(const unsigned long long *
 }
 // wave 0: the early pass is retired and the landed vector READ in front of the phase's first barrier (the LDS latency of the four
 // reads hides in the barrier), tested behind it; false = some element had not arrived (kr_pair_collect then polls them in)
+// (only the low dwords, which carry the phase bit, are read: 2 x NP / 64 registers across the barrier)
 template <int NP>
-__device__ __forceinline__ void kr_pair_check_load(const double2 *dst, double2 (&v)[NP / 64]) {
+__device__ __forceinline__ void kr_pair_check_load(const double2 *dst, unsigned (&v)[2 * (NP / 64)]) {
     const int lane = threadIdx.x & 63;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned *u = (const unsigned *)dst;
 #pragma unroll
-    for (int c = 0; c < NP / 64; ++c) v[c] = dst[64 * c + lane];
+    for (int c = 0; c < NP / 64; ++c) { v[2 * c] = u[(64 * c + lane) * 4]; v[2 * c + 1] = u[(64 * c + lane) * 4 + 2]; }
 }
 template <int NP>
-__device__ __forceinline__ bool kr_pair_check_test(const KrPairBox &box, const double2 (&v)[NP / 64]) {
+__device__ __forceinline__ bool kr_pair_check_test(const KrPairBox &box, const unsigned (&v)[2 * (NP / 64)]) {
     const unsigned phase = (((box.counter - 1u) >> 1) & 1u) ^ 1u;
-    bool ok = true;
+    unsigned all_and = 1u, all_or = 0u;
 #pragma unroll
-    for (int c = 0; c < NP / 64; ++c)
-        ok = ok && (((unsigned)__double2loint(v[c].x) & 1u) == phase) && (((unsigned)__double2loint(v[c].y) & 1u) == phase);
+    for (int c = 0; c < 2 * (NP / 64); ++c) { all_and &= v[c]; all_or |= v[c]; }
+    const bool ok = phase ? ((all_and & 1u) == 1u) : ((all_or & 1u) == 0u);
     return __all(ok);
 }
 
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
     // the control block H_1: columns [0, JSH) of the thread's slice in registers, [JSH, JS) in LDS (thread-major, conflict-free).
     // It is touched three times per step (phase-A product, two H(eps) updates), not in the rounds: with all of it in registers
     // the update kernel spilled (184-208 B of scratch at NR = 32; 72-140 B with half of it in LDS).
-    constexpr int JSH = (JS > 8) ? JS / 4 : JS;
+    constexpr int JSH = (JS > 8) ? JS / 8 : JS;
     __shared__ __attribute__((aligned(16))) double2 sH1[(JS > JSH) ? (JS - JSH) * T : 1];
 #define KR_H1R(jj) (((jj) < JSH) ? H1r[(jj) < JSH ? (jj) : 0] : sH1[((jj) < JSH ? 0 : (jj) - JSH) * T + tid].x)
 #define KR_H1I(jj) (((jj) < JSH) ? H1i[(jj) < JSH ? (jj) : 0] : sH1[((jj) < JSH ? 0 : (jj) - JSH) * T + tid].y)
@@ -319,16 +324,16 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
 #define KR_PAIR_PHASE(q_, vr_, vi_, dst_, ocollect_, odst_, early_)                                                      \
     {                                                                                                                    \
         unsigned long long tp_ = stamp ? __builtin_amdgcn_s_memtime() : 0; (void)tp_;                                    \
-        double2 chk_[NP / 64];                                                                                           \
-        /* known-pulse sweeps: the landed vector is read IN FRONT of the barrier (16.95 -> 16.05 us per step at C5); the update   \
-           kernel has no 16 registers to keep across it (it spilled 108 B and lost what the reads had gained): it reads behind */ \
-        if (!UPDATE && (ocollect_) && (early_) && wave == 0) kr_pair_check_load<NP>(odst_, chk_);                         \
+        unsigned chk_[2 * (NP / 64)];                                                                                    \
+        /* the landed vector's phase bits (low dwords only: 8 registers) are read IN FRONT of the barrier, where the LDS latency  \
+           hides in the barrier wait: C5 known-pulse step 16.95 -> 16.05 us, update step 19.35 -> 19.05 us (same-box A/B) */    \
+        if (KR_PAIR_PRE && (ocollect_) && (early_) && wave == 0) kr_pair_check_load<NP>(odst_, chk_);                     \
         kr_pair_deposit<NP, NR, JS>(box[q_], rb, owner, il, vr_, vi_, dst_);                                             \
         __syncthreads();                                                                                                 \
         KR_PROBE(prA)                                                                                                    \
         kr_pair_publish<NP, NR, JS>(box[q_], rb, dst_);                                                                  \
         if ((ocollect_) && wave == 0) {                                                                                  \
-            if (UPDATE && (early_)) kr_pair_check_load<NP>(odst_, chk_);                                                 \
+            if (!KR_PAIR_PRE && (early_)) kr_pair_check_load<NP>(odst_, chk_);                                           \
             KR_PROBE(prB)                                                                                                \
             const bool got_ = (early_) && (KR_PAIR_NOVERIFY || kr_pair_check_test<NP>(box[1 - (q_)], chk_));             \
             KR_PROBE(prC)                                                                                                \
