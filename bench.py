@@ -499,7 +499,9 @@ def main():
             pass
         bytes_upd = K_local * NT * 32.0 * N
         mfma_sweep = bool(info.get("matrix_core_sweep", 0))
-        kernel_name = "kr_mf_update" if mfma_sweep else ("kr_rowsplit_sweep" if info.get("rowsplit_R", 0) else "kr_sweep_update")
+        kernel_name = ("kr_mf_update" if mfma_sweep else
+                       ("kr_rowsplit_pair_sweep" if "kr_rowsplit_pair_sweep" in (plan or "") else "kr_rowsplit_sweep")
+                       if info.get("rowsplit_R", 0) else "kr_sweep_update")
         line = {
             "metric": METRIC_FMT % (N, NT, K_global),
             "value": value,
