@@ -113,6 +113,30 @@ __device__ __forceinline__ double kr_wave_sum(double v) {
     return ((r0 + r1) + r2) + r3;
 }
 
+// Two wave-wide sums at once: the same butterflies and the same order per value as kr_wave_sum (bitwise identical results), the two
+// dependent chains interleaved stage by stage -- the exchange sums L = 2 partials three times per step on its critical path, and
+// one chain after the other (what the compiler emits for two calls) costs twice the latency.
+__device__ __forceinline__ void kr_wave_sum2(double &a, double &b) {
+    double ta, tb;
+    ta = kr_dpp_mov<0xB1>(a);  tb = kr_dpp_mov<0xB1>(b);  a += ta; b += tb;
+    ta = kr_dpp_mov<0x4E>(a);  tb = kr_dpp_mov<0x4E>(b);  a += ta; b += tb;
+    ta = kr_dpp_mov<0x141>(a); tb = kr_dpp_mov<0x141>(b); a += ta; b += tb;
+    ta = kr_dpp_mov<0x140>(a); tb = kr_dpp_mov<0x140>(b); a += ta; b += tb;
+    const double a0 = kr_readlane_f64(a, 0), b0 = kr_readlane_f64(b, 0), a1 = kr_readlane_f64(a, 16), b1 = kr_readlane_f64(b, 16);
+    const double a2 = kr_readlane_f64(a, 32), b2 = kr_readlane_f64(b, 32), a3 = kr_readlane_f64(a, 48), b3 = kr_readlane_f64(b, 48);
+    double ra = a0 + a1, rb = b0 + b1;
+    ra += a2; rb += b2;
+    ra += a3; rb += b3;
+    a = ra; b = rb;
+}
+// all LMAX (2 or 4) values of an exchange; entries l >= L must hold finite numbers (zeros): pairs are summed together
+template <int LMAX>
+__device__ __forceinline__ void kr_wave_sum_all(double (&v)[LMAX], const int L) {
+    static_assert(LMAX == 2 || LMAX == 4, "pairs");
+    kr_wave_sum2(v[0], v[1]);
+    if (LMAX == 4) { if (L > 2) kr_wave_sum2(v[LMAX - 2], v[LMAX - 1]); }
+}
+
 // 1/j for a wave-uniform j without a memory access: lane j of every wave keeps 1/j in `mine`
 __device__ __forceinline__ double kr_rinv_lane(const double mine, const int j) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(mine), j);
@@ -542,8 +566,7 @@ __device__ __forceinline__ bool kr_gather_slots(const KrSweepArgs &a, const int 
             if (st != 0u || kr_realtime() - t0 > a.spin_ticks) return false;
         }
     }
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(tot[l]);
+    kr_wave_sum_all<LMAX>(tot, a.L);
     return true;
 }
 
@@ -579,22 +602,26 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
     // 1. the ROWS row owners of the workgroup deposit their partial sums
     if (writer) {
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) if (l < L) spart[l * ROWS + rowid] = part[l];
+        for (int l = 0; l < LMAX; ++l) if (l < L || l < 2) spart[l * ROWS + rowid] = (l < L) ? part[l] : 0.0;   // (the pair sums read l = 1 at L = 1)
     }
     __syncthreads();
 
-    if (SCHED == 1 && wave == 1 && !(P == 1 && a.world == 1)) {
-        double tot1[LMAX];
+    // workgroup partial: rows in a fixed order
+    auto own_partial = [&](double (&t)[LMAX]) {
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             double v = 0.0;
-            if (l < L) {
+            if (l < L || l < 2) {
 #pragma unroll
                 for (int r = 0; r < ROWS; r += 64) if (r + lane < ROWS) v += spart[l * ROWS + r + lane];
-                v = kr_wave_sum(v);
             }
-            tot1[l] = v;
+            t[l] = v;
         }
+        kr_wave_sum_all<LMAX>(t, L);
+    };
+    if (SCHED == 1 && wave == 1 && !(P == 1 && a.world == 1)) {
+        double tot1[LMAX];
+        own_partial(tot1);
         if (lane < 4 * KR_MAIL_REPLICAS && (lane & 3) < L && (!xlocal || (unsigned)(lane >> 2) == kr_xcc_id())) {   // lane = 4 * replica + l
             double v = 0.0;
 #pragma unroll
@@ -630,15 +657,10 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         bool ok_all = true;
         double tot[LMAX];
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) {  // workgroup partial: rows in a fixed order
-            double v = 0.0;
-            if (l < L) {
-#pragma unroll
-                for (int r = 0; r < ROWS; r += 64) if (r + lane < ROWS) v += spart[l * ROWS + r + lane];
-                v = kr_wave_sum(v);
-            }
-            tot[l] = v;
-        }
+        for (int l = 0; l < LMAX; ++l) tot[l] = 0.0;
+        // (SCHED 1: wave 1 publishes, and this wave needs the workgroup's own partial only when it IS the total -- two wave sums
+        //  less in front of its window work, i.e. the poll starts ~0.2 us earlier after the publish)
+        if (SCHED == 0 || KR_EARLY_POLL || (P == 1 && a.world == 1)) own_partial(tot);
         if (!(P == 1 && a.world == 1)) {
             // 2. publish this workgroup's partial
             if (SCHED == 0 && lane < 4 * KR_MAIL_REPLICAS && (lane & 3) < L) {   // lane = 4 * replica + l
@@ -657,8 +679,10 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 }
             }
 #ifdef KR_ARRIVALS  // diagnostic build: when did every workgroup publish / complete two exchanges in the middle of the sweep
-            const bool arr = a.debug != nullptr && lane == 0 && (n == a.NT / 2 || n == a.NT / 2 + 1);
-            if (arr) a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2)] = kr_realtime();
+            // (stamps stay in registers until the exchange is over: a store in front of the poll pass would be waited for by its vmcnt)
+            const bool arr = a.debug != nullptr && (n == a.NT / 2 || n == a.NT / 2 + 1);
+            unsigned long long arr_pub = 0, arr_wend = 0, arr_m0 = 0, arr_m1 = 0, arr_m2 = 0;
+            if (arr) arr_pub = kr_realtime();
 #endif
             const int pieces = (P * 8 * LMAX + 1023) >> 10;
             const bool early = EARLY && SCHED == 0 && a.world == 1 && P <= 64 * KR_POLL_CHUNKS && P > 1;
@@ -668,7 +692,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             KrMidPoll<LMAX> mid{a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + kr_xcc_id()) * KR_MAIL_RSTRIDE, spoll, pieces, lane, early, false};
             work(mid);
 #ifdef KR_ARRIVALS
-            if (arr) a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 1] = kr_realtime();
+            if (arr) { arr_wend = kr_realtime(); arr_m0 = __builtin_amdgcn_s_memtime(); }
 #endif
             bool done_early = false;
             if (mid.issued) {
@@ -682,7 +706,13 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             const unsigned long long t0 = kr_realtime();
             unsigned spins = 0;
             for (; a.world == 1 && !done_early;) {
+#ifdef KR_ARRIVALS
+                if (arr) arr_m1 = __builtin_amdgcn_s_memtime();
+#endif
                 const bool ok = kr_poll_pass<LMAX>(a, lpar, phase, lane, tot, sgran);
+#ifdef KR_ARRIVALS
+                if (arr) arr_m2 = __builtin_amdgcn_s_memtime();
+#endif
                 if (__all(ok)) break;
                 if ((++spins & 63u) == 0u) {
                     const unsigned st = __hip_atomic_load((kr_gu32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -698,12 +728,14 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 }
                 __builtin_amdgcn_s_sleep(KR_POLL_SLEEP);
             }
-            if (a.world == 1) {
-#pragma unroll
-                for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(tot[l]);
-            }
+            if (a.world == 1) kr_wave_sum_all<LMAX>(tot, L);
 #ifdef KR_ARRIVALS
-            if (arr) { a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 2] = kr_realtime(); a.debug[8 + (size_t)wg * 8 + 4 * (n - a.NT / 2) + 3] = spins + (done_early ? 100u : 0u); }
+            if (arr && lane == 0) {   // word 3: passes | cycles of the last pass << 8 | cycles window end -> sums done << 32 (s_memtime)
+                const unsigned long long m3 = __builtin_amdgcn_s_memtime();
+                unsigned long long *d = a.debug + 8 + (size_t)wg * 8 + 4 * (n - a.NT / 2);
+                d[0] = arr_pub; d[1] = arr_wend; d[2] = kr_realtime();
+                d[3] = (unsigned long long)((spins + (done_early ? 100u : 0u)) & 255u) | (((arr_m2 - arr_m1) & 0xffffffull) << 8) | (((m3 - arr_m0) & 0xffffffull) << 32);
+            }
 #endif
 
             // 4. inter-GPU hop, receiving side (the sending side is wave 2 of workgroup 0, above): every workgroup polls
@@ -750,8 +782,9 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                kr_wave_sum_all<LMAX>(gt, L);   // same tree on every GPU: bitwise identical totals
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l) tot[l] = kr_wave_sum(gt[l]);  // same tree on every GPU: bitwise identical totals
+                for (int l = 0; l < LMAX; ++l) tot[l] = gt[l];
             }
         } else {
             KrMidPoll<LMAX> nomid{nullptr, nullptr, 0, 0, false, false};

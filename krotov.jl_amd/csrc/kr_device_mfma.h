@@ -311,8 +311,7 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
                     if (l < L && ((gx.present >> l) & 1u)) part[l] = fma(-cl[l][t], psi[0][t], part[l]);
             }
         }
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) part[l] = kr_wave_sum(part[l]);   // fixed order: bitwise reproducible
+        kr_wave_sum_all<LMAX>(part, L);   // fixed order: bitwise reproducible
         auto window = [&](auto &mid) {
             if (HERM) {
                 products(0);   // (no early poll pass here -- mid() of kr_exchange: measured +0.2 % at two tiles, +0.9 % at one)

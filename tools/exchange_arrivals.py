@@ -26,7 +26,8 @@ a = eng.debug_arrivals(P).astype(np.int64)
 print(cfg, {k: info[k] for k in ("workgroups", "exchange_poll_delay", "hermitian_controls_path", "matrix_core_sweep")})
 tick = 10.0  # ns
 for e in range(2):
-    pub, wend, done, passes = a[:, e, 0], a[:, e, 1], a[:, e, 2], a[:, e, 3].copy()
+    pub, wend, done, passes = a[:, e, 0], a[:, e, 1], a[:, e, 2], (a[:, e, 3] & 255).copy()
+    last_pass, wend_to_sum = (a[:, e, 3] >> 8) & 0xFFFFFF, (a[:, e, 3] >> 32) & 0xFFFFFF
     early = passes >= 100
     passes[early] -= 101   # an early hit needs no register pass
     print("   early pass (LDS-DMA at publish time) hit in %d of %d workgroups; by XCD: %s" % (early.sum(), P, " ".join("%2d" % early[np.arange(P) % 8 == x].sum() for x in range(8))))
@@ -44,6 +45,8 @@ for e in range(2):
     print("   window work by XCD (ns, median):        " + " ".join("%4.0f" % (np.median((wend - pub)[xcd == x]) * tick) for x in range(8)))
     print("   poll (window end -> done) by XCD (ns):   " + " ".join("%4.0f" % (np.median((done - wend)[xcd == x]) * tick) for x in range(8)))
     print("   poll passes by XCD (median):             " + " ".join("%4.1f" % (np.median(passes[xcd == x]) + 1) for x in range(8)))
+    print("   LAST pass, loads + accumulate (cycles):  " + " ".join("%4.0f" % np.median(last_pass[xcd == x]) for x in range(8)))
+    print("   window end -> sums done (cycles):        " + " ".join("%4.0f" % np.median(wend_to_sum[xcd == x]) for x in range(8)))
     print("   completion offset by XCD (ns, median): " + " ".join("%4.0f" % ((np.median(done[xcd == x]) - t0) * tick) for x in range(8)))
 if a[:, 1, 0].any():
     xcd = np.arange(P) % 8
