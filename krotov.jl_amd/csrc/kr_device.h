@@ -978,7 +978,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) part[l] = 0.0;
         // H(eps_guess) of this step (eps_guess is known in advance; exact, no drift), b = H(eps_guess) psi, a_l = H_l psi
-        auto form_and_apply = [&]() {
+        auto form_E = [&]() {
 #pragma unroll
             for (int jj = 0; jj < JS; ++jj) {
                 double r, im;
@@ -992,11 +992,15 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 Er[jj] = r;
                 Ei[jj] = im;
             }
+        };
+        auto apply_b = [&]() {
+#pragma unroll
+            for (int q = 0; q < KT; ++q) kr_row_dot<JS, JQ>(Er, Ei, &sx[cur][q * SG + team][xoff], a0r[q], a0i[q]);
+        };
+        auto apply_controls = [&]() {
 #pragma unroll
             for (int q = 0; q < KT; ++q) {
-                const int tq = q * SG + team;
-                const double2 *src = &sx[cur][tq][xoff];
-                kr_row_dot<JS, JQ>(Er, Ei, src, a0r[q], a0i[q]);
+                const double2 *src = &sx[cur][q * SG + team][xoff];
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) {
                     alr[q][l] = 0.0; ali[q][l] = 0.0;
@@ -1005,8 +1009,9 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
             }
         };
         if (!HERM) {
-            // ---- phase A: b, a_l and the partial sums Im<chi|H_l|psi> ----
-            form_and_apply();
+            // ---- phase A: a_l = H_l psi and the partial sums Im<chi|H_l|psi>; H(eps_guess) and b = H(eps_guess) psi, which only the
+            //      free first application needs, wait for the window (round 3: they used to sit in front of the exchange) ----
+            apply_controls();
 #pragma unroll
             for (int q = 0; q < KT; ++q) {
                 const double2 chi = sc[n & 1][q * SG + team][pi_];
@@ -1025,8 +1030,10 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
             }
         }
         auto window = [&](auto &mid) {
+            form_E();
+            apply_b();
             if (HERM) {
-                form_and_apply();
+                apply_controls();
                 if (KR_EARLY_POLL) mid();   // (polling wave: early poll pass, kr_exchange)
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {

@@ -288,12 +288,39 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
                 kr_mf_multi<TILES, 1 + LMAX, true, false>(sH0, Hr, Hi, &KR_SX_RD(st)[0][0], boff, kb0, D[st]);
             }
         };
+        // the same split in two: the control products (all the partial sums need) and the drift product (which only the free first
+        // application needs: it moves into the exchange's window -- round 3; it used to sit in front of the exchange)
+        auto products_ctrl = [&](const int st) {
+            if (L == 1) {
+                double dd[1][TILES];
+                kr_mf_multi<TILES, 1, false, false>(nullptr, Hr, Hi, &KR_SX_RD(st)[0][0], boff, kb0, dd);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    D[st][1][t] = dd[0][t];
+#pragma unroll
+                    for (int l = 1; l < LMAX; ++l) D[st][1 + l][t] = 0.0;
+                }
+            } else {
+                double dc[LMAX][TILES];
+                kr_mf_multi<TILES, LMAX, false, false>(nullptr, Hr, Hi, &KR_SX_RD(st)[0][0], boff, kb0, dc);
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l)
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) D[st][1 + l][t] = dc[l][t];
+            }
+        };
+        auto product_drift = [&](const int st) {
+            double dd[1][TILES];
+            kr_mf_multi<TILES, 1, true, false>(sH0, Hr, Hi, &KR_SX_RD(st)[0][0], boff, kb0, dd);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) D[st][0][t] = dd[0][t];
+        };
         if (!HERM) {
             // ---- phase A: Im<chi|H_l|psi> = Im(conj(chi) a), a = H_l psi = i D  ->  chi_r D_r + chi_i D_i, lane by lane;
             //      set after set into the same partial sums ----
 #pragma unroll
             for (int st = 0; st < SETS; ++st) {
-                products(st);
+                products_ctrl(st);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     const double chc = KR_SC_AT(st, n)[t][doff].y;
@@ -320,6 +347,10 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
                 for (int l = 0; l < LMAX; ++l)
                     if (l < L && n + 1 < NT)
                         kr_mf_apply<TILES>(Hr[l], Hi[l], &sc[(n + 1) & 1][0][0], boff, kb0, cl[l]);
+            } else {
+                (void)mid;
+#pragma unroll
+                for (int st = 0; st < SETS; ++st) product_drift(st);
             }
         };
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tA += t - t_prev; t_prev = t; }
