@@ -583,7 +583,7 @@ template <int LMAX, int ROWS, int SCHED = 0, class F = KrNoWork>
 __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, const int wg, const bool writer,
                                             const int rowid, const double (&part)[LMAX], double (&total)[LMAX],
                                             double *spart /*[LMAX][ROWS]*/, double *stot /*[LMAX+1]*/, F work = F(),
-                                            const bool xlocal = false) {
+                                            const bool xlocal = false, const bool deposited = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, P = a.P;
     // Tags count exchange events over the life of the handle (32-bit, wrapping); the buffer parity is taken from
@@ -599,12 +599,15 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
     constexpr bool EARLY = !KrIsNoWork<F>::value;   // a window exists: overlap the first poll pass with it
     __shared__ __attribute__((aligned(16))) unsigned long long spoll[EARLY ? 64 * KR_POLL_CHUNKS * LMAX : 2];
 
-    // 1. the ROWS row owners of the workgroup deposit their partial sums
-    if (writer) {
+    // 1. the ROWS row owners of the workgroup deposit their partial sums (`deposited`, workgroup-uniform: the caller has done that
+    //    already, in front of a barrier of its own -- kr_sweep_update's window variant deposits with the step's last barrier)
+    if (!deposited) {
+        if (writer) {
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) if (l < L || l < 2) spart[l * ROWS + rowid] = (l < L) ? part[l] : 0.0;   // (the pair sums read l = 1 at L = 1)
+            for (int l = 0; l < LMAX; ++l) if (l < L || l < 2) spart[l * ROWS + rowid] = (l < L) ? part[l] : 0.0;   // (the pair sums read l = 1 at L = 1)
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // workgroup partial: rows in a fixed order
     auto own_partial = [&](double (&t)[LMAX]) {
@@ -797,9 +800,14 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         }
     }
     __syncthreads();
+    // totals and flag in ONE LDS round trip: the caller returns on a bad flag, and left alone the compiler reads the flag, branches,
+    // and only then asks for the totals (a second LDS latency on the critical path of every step)
+    const double flag = stot[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) total[l] = stot[l];
-    return stot[LMAX] != 0.0;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) asm volatile("" :: "v"(total[l]));
+    return flag != 0.0;
 }
 
 // =============================================================================================
@@ -1020,8 +1028,9 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 for (int l = 0; l < LMAX; ++l)
                     if (l < L && ((gx.present >> l) & 1u)) part[l] += chi.x * ali[q][l] - chi.y * alr[q][l];
             }
-        } else {
-            // ---- Im<H_l chi|psi> = c_r psi_i - c_i psi_r from the carried c_l(n); everything else moves into the window ----
+        } else if (n == 0) {
+            // ---- Im<H_l chi|psi> = c_r psi_i - c_i psi_r from the carried c_l(n); everything else moves into the window.
+            //      (Steps n > 0: done and deposited at the end of step n - 1, deposit_next below.) ----
 #pragma unroll
             for (int q = 0; q < KT; ++q) {
 #pragma unroll
@@ -1029,6 +1038,26 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                     if (l < L && ((gx.present >> l) & 1u)) part[l] += clr[q][l] * pim[q] - cli[q][l] * pr[q];
             }
         }
+        // HERM: the partial sums of step n + 1 need c_l(n+1) (this step's window) and psi(t_{n+1}) (this step's result), both in
+        // this thread's registers when the step ends: the row owners deposit them together with psi(t_{n+1}), in front of the
+        // step's LAST barrier -- the next exchange starts without a deposit and a barrier of its own.
+        auto deposit_next = [&]() {
+            if (HERM && n + 1 < NT) {
+                double pn[LMAX];
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) pn[l] = 0.0;
+#pragma unroll
+                for (int q = 0; q < KT; ++q) {
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l)
+                        if (l < L && ((gx.present >> l) & 1u)) pn[l] += clr[q][l] * pim[q] - cli[q][l] * pr[q];
+                }
+                if (writer) {
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) if (l < L || l < 2) spart[l * 64 + rowid] = (l < L) ? pn[l] : 0.0;
+                }
+            }
+        };
         auto window = [&](auto &mid) {
             form_E();
             apply_b();
@@ -1050,7 +1079,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 
         // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
         double du[LMAX];
-        if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot, window, XLOC ? xlocal : false)) return;
+        if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot, window, XLOC ? xlocal : false, HERM && n > 0)) return;
 
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 
@@ -1141,6 +1170,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
                 for (int c = 0; c < CH; ++c) if (m_tq[c] >= 0) sc[(n + 1 + HERM) & 1][m_tq[c]][m_i[c] + m_i[c] / JS] = cpf[c];
             }
+            if (s == 1) deposit_next();
             __syncthreads();
             cur ^= 1;
         }
@@ -1167,7 +1197,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
                     for (int c = 0; c < CH; ++c) if (m_tq[c] >= 0) sc[(n + 1 + HERM) & 1][m_tq[c]][m_i[c] + m_i[c] / JS] = cpf[c];
                 }
-                if (j == 1 && sub == s - 1) __syncthreads();   // end of the step: states and chi change hands between waves
+                if (j == 1 && sub == s - 1) { deposit_next(); __syncthreads(); }   // end of the step: states and chi change hands between waves
                 else kr_team_sync<RT>();
                 w ^= 1;
             }
