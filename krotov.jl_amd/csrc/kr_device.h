@@ -1205,7 +1205,9 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         }
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tB += t - t_prev; t_prev = t; }
 
-        // memory wave: forward storage slot n+1 <- psi(t_{n+1}) (coalesced 16-B stores from LDS)
+        // memory wave: forward storage slot n+1 <- psi(t_{n+1}) (coalesced 16-B stores from LDS).  (Issued at the top of the NEXT step
+        // instead -- so that the loop head's vmcnt(0) does not hold the memory wave until the acknowledgement -- it measured slower:
+        // C3 5.25 -> 5.37, C4 9.93 -> 10.00 us per step, same box.)
         if (memwave && a.store) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
@@ -1255,8 +1257,9 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
 #define KR_CASE(LM, KTv)                                                                          \
     if (lmax == LM && kt == KTv) {                                                                \
         if (kind == 0) kr_launch_kernel((kr_sweep_known<NP, LM, KTv>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
-        else if ((kind & 15) == 1 && (kind & 128)) {  /* one-XCD placement (P <= 32: classic schedule, general variant, no calibration) */ \
-            kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 0, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
+        else if ((kind & 15) == 1 && (kind & 128)) {  /* one-XCD placement (P <= 32, no calibration): window variant (wave 1 publishes) or general variant (classic schedule) */ \
+            if (kind & 64) kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 1, 0, 1, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
+            else kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 0, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
         } \
         else if ((kind & 15) == 1) {  /* update sweep: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 */ \
             switch (kind >> 4) { \

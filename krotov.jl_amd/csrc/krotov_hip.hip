@@ -609,7 +609,11 @@ static void decide_herm(kr_handle *h, const kr_config *cfg) {
     //  dot + exchange --, with two tiles its five products outlast the exchange: C4 11.74 vs 11.35 us per step)
     h->herm = (mode == 2) || (mode == 1 && (h->mfma_sweep ? h->KT == 2 : h->KT == 1) && h->P >= 64 && h->NP <= 64);
     if (h->sets > 1) h->herm = false;   // several sets per workgroup: general variant only
-    if (h->wg_stride > 1) h->herm = false;   // one-XCD placement (P <= 32): kr_sweep_update<.., XLOC = 1> is the general variant (the window variant measured the same there: C2 3.55 vs 3.50 us per step)
+    // one-XCD placement (P <= 32): the window variant with wave 1 publishing (kr_sweep_update<.., SCHED 1, HERM 1, XLOC 1>; round 3:
+    // with the next step's partial sums deposited by the step's last barrier the publish is the FIRST thing a step does, and
+    // phase A hides behind the L2 round trips -- C2 3.50 -> see DESIGN.md) or the general variant with the classic schedule
+    // (N = 64: five row-dots of window outlast the L2 round trips: 5.00 vs 5.16 us per step at K = 16 -- general variant there)
+    if (h->wg_stride > 1) h->herm = (mode != 0) && h->KT == 1 && h->NP <= 32 && env_int("KROTOV_HIP_XLOC_HERM", 1) != 0;
     if (h->mfma_sweep && h->LMAXv == 4 && h->KT == 4) h->herm = false;   // that instantiation spills (212 B): general variant
     if (h->rowsplit || h->NP > 64) h->herm = false;
     for (int g = 0; g < G && h->herm; ++g) {
@@ -1532,7 +1536,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
         if (h->mfma_sweep) HIPCHK(h, kr_launch_mf64(h->LMAXv, (h->KT / 2) | (h->sets > 1 ? h->sets << 8 : 0), kind, h->P, h->stream, &a));
         else {
             a.wg_stride = (h->NP <= 64 && !calib_steps) ? h->wg_stride : 1;
-            if (a.wg_stride > 1) kind = 1 | 128;   // kr_sweep_update<.., XLOC = 1>: classic schedule, general variant
+            if (a.wg_stride > 1) kind = 1 | 128 | (h->herm ? 64 : 0);   // kr_sweep_update<.., XLOC = 1>: general variant, classic schedule / window variant, wave 1 publishes
             HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P * a.wg_stride, h->stream, &a));
         }
     }
