@@ -554,37 +554,42 @@ __global__ __launch_bounds__(256, 1) void kr_mf_apply_sweep(const KrSweepArgs a)
         for (int c = 0; c < CH; ++c)
             if (m_ok[c]) a.store[(size_t)slot0 * slab + tile_base + lane + 64 * c] = a.init[tile_base + lane + 64 * c];
     }
-    // A operands: TWO steps in flight (ua, ub) next to the set in use (three: C4 1.88 -> 1.85 ms per sweep, K = 512 1.37 -> 1.41).  With one step in flight a step took the load latency
-    // plus the transfer of the 64 KB (1.92 us at two tiles against ~0.5 us of MFMA work): the loads of step n + 1 were only
-    // issued once those of step n had arrived.
-    double2 ua[16], ub[16];
-    {
-        const int n0 = (a.dir > 0) ? 0 : (NT - 1);
-        const double2 *U = Umf + (size_t)n0 * 4096 + (size_t)wave * 1024 + lane;
-#pragma unroll
-        for (int sl = 0; sl < 16; ++sl) ua[sl] = U[sl * 64];
-        if (NT > 1) {
-            const int n1 = (a.dir > 0) ? 1 : (NT - 2);
-            const double2 *U1 = Umf + (size_t)n1 * 4096 + (size_t)wave * 1024 + lane;
-#pragma unroll
-            for (int sl = 0; sl < 16; ++sl) ub[sl] = U1[sl * 64];
-        }
+    // A operands: two register sets, each REFILLED at the end of the step that used it (for the step after next), as asm loads
+    // with written-out waits (round 3).  With compiler-visible loads the set in use was copied out of the way of its own refill --
+    // and a copy of registers with loads in flight is a vmcnt(0): however many steps were "in flight", the loads of step n + 1
+    // were only issued once those of step n had arrived (1.9 us per step at two tiles against ~0.5 us of MFMA work; a third set
+    // bought 2 %).  vmcnt(16): everything but the youngest set has landed (the memory wave's stores only make that stricter).
+    typedef double kr_v2d __attribute__((ext_vector_type(2)));   // (a vector type: asm register operands cannot be structs)
+    kr_v2d ua[16], ub[16];
+#define KR_MF_LD4(set_, g_, p_)                                                                                        \
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"                 \
+                 "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"          \
+                 : "=&v"(set_[4 * (g_)]), "=&v"(set_[4 * (g_) + 1]), "=&v"(set_[4 * (g_) + 2]), "=&v"(set_[4 * (g_) + 3]) : "v"(p_) : "memory");
+#define KR_MF_FILL(set_, step_)                                                                                        \
+    {                                                                                                                  \
+        const int sc_ = ((step_) < NT) ? (step_) : (NT - 1);   /* past the end: the last step's operands again */         \
+        const int nn_ = (a.dir > 0) ? sc_ : (NT - 1 - sc_);                                                            \
+        const double2 *U_ = Umf + (size_t)nn_ * 4096 + (size_t)wave * 1024 + lane;                                     \
+        const double2 *U1_ = U_ + 256, *U2_ = U_ + 512, *U3_ = U_ + 768;                                               \
+        KR_MF_LD4(set_, 0, U_) KR_MF_LD4(set_, 1, U1_) KR_MF_LD4(set_, 2, U2_) KR_MF_LD4(set_, 3, U3_)                 \
     }
+#define KR_MF_WAIT(s_)                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(16)" : "+v"(s_[0]), "+v"(s_[1]), "+v"(s_[2]), "+v"(s_[3]), "+v"(s_[4]), "+v"(s_[5]), "+v"(s_[6]), "+v"(s_[7]), \
+                 "+v"(s_[8]), "+v"(s_[9]), "+v"(s_[10]), "+v"(s_[11]), "+v"(s_[12]), "+v"(s_[13]), "+v"(s_[14]), "+v"(s_[15]) :: "memory");
+    KR_MF_FILL(ua, 0)
+    KR_MF_FILL(ub, 1)
     __syncthreads();
     int cur = 0;
     double psi[TILES];
 #define KR_MF_APPLY_STEP(step_, un_)                                                                                   \
     {                                                                                                                  \
         const int n = (a.dir > 0) ? (step_) : (NT - 1 - (step_));                                                      \
+        KR_MF_WAIT(un_)                                                                                                \
         double Ar[16], Ai[16];                                                                                         \
         _Pragma("unroll") for (int sl = 0; sl < 16; ++sl) { Ar[sl] = un_[sl].x; Ai[sl] = un_[sl].y; }                  \
-        if ((step_) + 2 < NT) {   /* operands of the step after next */                                                \
-            const int n2 = (a.dir > 0) ? ((step_) + 2) : (NT - 3 - (step_));                                           \
-            const double2 *U = Umf + (size_t)n2 * 4096 + (size_t)wave * 1024 + lane;                                   \
-            _Pragma("unroll") for (int sl = 0; sl < 16; ++sl) un_[sl] = U[sl * 64];                                    \
-        }                                                                                                              \
         kr_mf_apply<TILES>(Ar, Ai, &sx[cur][0][0], boff, kb0, psi);                                                    \
         _Pragma("unroll") for (int t = 0; t < TILES; ++t) kr_mf_put(sx[cur ^ 1][t], doff, zoff, zs, psi[t]);           \
+        KR_MF_FILL(un_, (step_) + 2)                                                                                   \
         __syncthreads();                                                                                               \
         cur ^= 1;                                                                                                      \
         if (memwave && a.store) {                                                                                      \
@@ -598,7 +603,11 @@ __global__ __launch_bounds__(256, 1) void kr_mf_apply_sweep(const KrSweepArgs a)
         KR_MF_APPLY_STEP(step, ua)
         if (step + 1 < NT) KR_MF_APPLY_STEP(step + 1, ub)
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last fills: nothing reads them)
 #undef KR_MF_APPLY_STEP
+#undef KR_MF_FILL
+#undef KR_MF_LD4
+#undef KR_MF_WAIT
     if (a.fin && memwave) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
