@@ -343,10 +343,20 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
             if (HERM) {
                 products(0);   // (no early poll pass here -- mid() of kr_exchange: measured +0.2 % at two tiles, +0.9 % at one)
                 (void)mid;
+                // c_l(n+1) = -i H_l chi(t_{n+1}): the control matrices share their B operands (one pass over chi; round 3 -- two
+                // separate products cost 2 x 1.0 k / 1.8 k cycles at one / two tiles, together 1.3 k / 2.4 k)
+                if (n + 1 < NT) {
+                    if (L == 1) {
+                        kr_mf_apply<TILES>(Hr[0], Hi[0], &sc[(n + 1) & 1][0][0], boff, kb0, cl[0]);
+                    } else {
+                        double dc[LMAX][TILES];
+                        kr_mf_multi<TILES, LMAX, false, false>(nullptr, Hr, Hi, &sc[(n + 1) & 1][0][0], boff, kb0, dc);
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l)
-                    if (l < L && n + 1 < NT)
-                        kr_mf_apply<TILES>(Hr[l], Hi[l], &sc[(n + 1) & 1][0][0], boff, kb0, cl[l]);
+                        for (int l = 0; l < LMAX; ++l)
+#pragma unroll
+                            for (int t = 0; t < TILES; ++t) if (l < L) cl[l][t] = dc[l][t];
+                    }
+                }
             } else {
                 (void)mid;
 #pragma unroll
