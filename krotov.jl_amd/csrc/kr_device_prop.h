@@ -314,6 +314,102 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
         Ai[t] = -fs * hr;
         nAi[t] = fs * hr;
     }
+    int cur = 0;
+    // ---- Paterson-Stockmeyer evaluation for 5 <= m <= 7 (round 3): p(A) = B0 + B1 A^4, Bk = c_4k + c_4k+1 A + c_4k+2 A^2 + c_4k+3 A^3
+    //      -- four products (A^2, A^3, A^4, B1 A^4) against m - 1 = 4..6 Horner rounds.  (A second level for degrees 8..11 keeps B1 in
+    //      the D layout as well and spills: those degrees -- Taylor without the economized rows -- stay with the Horner form.)
+    //      Left operands are register fragments (A, A^2 and the Bk are linear combinations of the fragments of A, A^2, A^3: all
+    //      powers commute, so the Bk go to the LEFT of A^4), right operands come from the two LDS buffers; products leave the
+    //      matrix cores in the D layout, B0 is accumulated there as the powers appear, and a power needed as a left
+    //      operand takes the round trip through LDS that the squaring rounds below take as well.  Same coefficients as the Horner
+    //      form (c_0 = a_0, c_1 = a_1 resp. 1, c_j = c_{j-1} g_j), results differ by rounding only.
+    const bool ps = (a.use_mfma & 2) != 0 && m >= 5 && m <= 7;
+    if (ps) {
+        double c[8];
+        c[0] = eco.a0;
+        c[1] = kr_rinv_lane(my_g, 1);
+#pragma unroll
+        for (int j = 2; j < 8; ++j) c[j] = (j <= m) ? c[j - 1] * kr_rinv_lane(my_g, j) : 0.0;
+        // one product: (Lr + i Li) x (buffer b)  ->  sink(ct, re[4], im[4]) per column tile, D layout (row 16 w + lk + 4 r, column 16 ct + li)
+        auto product = [&](const double (&Lr)[16], const double (&Li)[16], const int b, auto sink) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                kr_d4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0}, pc = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const double br = KR_YR(b)[(4 * t + lk) * KR_YS + 16 * ct + li];
+                    const double bi = KR_YI(b)[(4 * t + lk) * KR_YS + 16 * ct + li];
+                    pa = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[t], br, pa, 0, 0, 0);
+                    pb = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[t], bi, pb, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[t], bi, pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[t], br, pc, 0, 0, 0);
+                }
+                sink(ct, pa - pb, pc);
+            }
+        };
+        auto store_d = [&](const int b, const int ct, const kr_d4 vr, const kr_d4 vi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                KR_YR(b)[(16 * w + lk + 4 * r) * KR_YS + 16 * ct + li] = vr[r];
+                KR_YI(b)[(16 * w + lk + 4 * r) * KR_YS + 16 * ct + li] = vi[r];
+            }
+        };
+        auto load_frag = [&](const int b, double (&Fr)[16], double (&Fi)[16]) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { Fr[t] = KR_YR(b)[row * KR_YS + 4 * t + lk]; Fi[t] = KR_YI(b)[row * KR_YS + 4 * t + lk]; }
+        };
+        // A -> buffer 0 (fragment positions)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { KR_YR(0)[row * KR_YS + 4 * t + lk] = Ar[t]; KR_YI(0)[row * KR_YS + 4 * t + lk] = Ai[t]; }
+        __syncthreads();
+        // B0 in the D layout: identity and A terms
+        kr_d4 b0r[4], b0i[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = 16 * w + lk + 4 * r, ocol = 16 * ct + li;
+                const double ar = KR_YR(0)[orow * KR_YS + ocol], ai = KR_YI(0)[orow * KR_YS + ocol];
+                const double dg = (orow == ocol) ? 1.0 : 0.0;
+                b0r[ct][r] = fma(c[1], ar, c[0] * dg); b0i[ct][r] = c[1] * ai;
+            }
+        }
+        // A^2 = A A -> buffer 1
+        product(Ar, Ai, 0, [&](const int ct, const kr_d4 vr, const kr_d4 vi) {
+            store_d(1, ct, vr, vi);
+            b0r[ct] += c[2] * vr; b0i[ct] += c[2] * vi;
+        });
+        __syncthreads();
+        double A2r[16], A2i[16];
+        load_frag(1, A2r, A2i);
+        // A^3 = A A^2 -> buffer 0 (A itself is no longer needed there: its readers were the product above)
+        product(Ar, Ai, 1, [&](const int ct, const kr_d4 vr, const kr_d4 vi) {
+            store_d(0, ct, vr, vi);
+            b0r[ct] += c[3] * vr; b0i[ct] += c[3] * vi;
+        });
+        __syncthreads();
+        double Fr[16], Fi[16];   // A^3 fragments, then the left operand B1
+        load_frag(0, Fr, Fi);
+        __syncthreads();         // everybody holds its A^3 fragments: buffer 0 may take A^4
+        // A^4 = A^2 A^2 -> buffer 0
+        product(A2r, A2i, 1, [&](const int ct, const kr_d4 vr, const kr_d4 vi) { store_d(0, ct, vr, vi); });
+        // left operand of the last product: B1 = c_4 + c_5 A + c_6 A^2 + c_7 A^3, as fragments
+        {
+            constexpr int kb = 4;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const double dg = (row == 4 * t + lk) ? 1.0 : 0.0;
+                const double fr = fma(c[kb + 3], Fr[t], fma(c[kb + 2], A2r[t], fma(c[kb + 1], Ar[t], c[kb] * dg)));
+                const double fi = fma(c[kb + 3], Fi[t], fma(c[kb + 2], A2i[t], c[kb + 1] * Ai[t]));
+                Fr[t] = fr; Fi[t] = fi;
+            }
+        }
+        __syncthreads();         // A^4 complete in buffer 0
+        // U = B0 + B1 A^4 -> buffer 1 (its A^2 has been read by everybody: the barrier above)
+        product(Fr, Fi, 0, [&](const int ct, const kr_d4 vr, const kr_d4 vi) { store_d(1, ct, b0r[ct] + vr, b0i[ct] + vi); });
+        __syncthreads();
+        cur = 1;
+    } else
     // Horner round j = m needs no product: Y_{m-1} = c I + f_m A, written from the A fragments (c = a_0 when it is also the last)
     {
         const double fm = kr_rinv_lane(my_g, m), idm = (m == 1) ? eco.a0 : 1.0;
@@ -326,9 +422,8 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
     }
     __syncthreads();
 
-    int cur = 0;
     const int rounds = (m - 1) + q;
-    for (int rd = 0; rd < rounds; ++rd) {
+    for (int rd = ps ? (m - 1) : 0; rd < rounds; ++rd) {   // (Paterson-Stockmeyer has done the polynomial: squarings only)
         const bool horner = (rd < m - 1);
         const int j = m - 1 - rd;  // Horner index m-1..1
         const double f = horner ? kr_rinv_lane(my_g, j) : 1.0;

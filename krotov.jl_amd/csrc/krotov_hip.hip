@@ -1205,7 +1205,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.tol = h->tol;
     a.spin_ticks = h->spin_ticks;
     memcpy(a.thr, h->thr, sizeof a.thr);
-    a.use_mfma = h->use_mfma ? 1 : 0;
+    a.use_mfma = h->use_mfma ? (1 | (env_int("KROTOV_HIP_EXPM_PS", 1) != 0 ? 2 : 0)) : 0;   // bit 1: Paterson-Stockmeyer form of the matrix-core propagator build
     a.gmail = h->gmail_d;
     a.xcd_group = h->xcd_group ? 1 : 0;
     a.pack_stride = h->pack_stride;

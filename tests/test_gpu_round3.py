@@ -323,3 +323,28 @@ def test_tile_sets_with_per_trajectory_generators_and_masks():
             psi[ks] = psi[ks] @ o.step_propagator(H0[g], Hc[g], eps_o[:, n], dt).T
     assert np.max(np.abs(eps_o - eps)) > 1e-5
     assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < TOL_GA and np.max(np.abs(psiT1 - psi)) < TOL_STATE
+
+
+def test_propagator_build_paterson_stockmeyer_agrees_with_horner_and_oracle(monkeypatch):
+    """The matrix-core propagator build (kr_expm_mfma64) evaluates the step polynomial of degree 5..7 in the Paterson-Stockmeyer
+    form (four products) instead of Horner (m - 1): same coefficients, so the known-pulse sweeps
+    (/root/reference/src/optimize.jl:247-265, 303-317) must agree with the Horner build to rounding and with the oracle's exact step
+    propagator to the usual tolerance -- Hermitian generator (economized rows, m = 7) and with the rows switched off (Taylor)."""
+    import krotov_oracle as o
+    for econ in ("1", "0"):
+        monkeypatch.setenv("KROTOV_HIP_ECON", econ)
+        p = wl.dense_problem(64, 24, 6, 2, 4711, 0.05, 0.04)
+        out = {}
+        for ps in ("1", "0"):
+            monkeypatch.setenv("KROTOV_HIP_EXPM_PS", ps)
+            with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 6) as eng:
+                assert eng.info()["precomputed_propagators"] == 1
+                eng.set_initial_states(p["psi0"])
+                psiT = eng.forward(p["eps"])
+                _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+                eps_new, ga, psiT2 = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+                out[ps] = (psiT.copy(), eps_new.copy(), psiT2.copy())
+        for a, b in zip(out["1"], out["0"]):
+            assert np.max(np.abs(a - b)) < 5e-14
+        psi_ref, _ = o.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False)
+        assert np.max(np.abs(out["1"][0] - psi_ref)) < 1e-11
