@@ -9,6 +9,7 @@
 #pragma once
 #include "kr_device.h"
 
+typedef unsigned int kr_su4 __attribute__((ext_vector_type(4)));
 template <int NP, int LMAX, int KT>
 struct KrGeomS {
     static constexpr int JQ = 4;
@@ -26,7 +27,7 @@ struct KrGeomS {
 //   o[q][0]      = row sum of H(eps) x_q,   H(eps) = H0 + sum_l e_l H_l
 //   o[q][1 + l]  = row sum of H_l x_q       (only when NOUT == 1 + LMAX: phase A of the update sweep)
 template <int JS, int JQ, int RT, int LMAX, int KT, int NOUT>
-__device__ __forceinline__ void kr_stream_rows(const double2 *__restrict__ Hpack, const int tt, const int L,
+__device__ __forceinline__ void kr_stream_rows(const __amdgpu_buffer_rsrc_t rsrc, const int tt, const int L,
                                                const double (&e)[LMAX], const double2 *const (&xp)[KT],
                                                double (&outr)[KT][NOUT], double (&outi)[KT][NOUT]) {
     double ar[KT][NOUT], br[KT][NOUT], ai[KT][NOUT], bi[KT][NOUT];
@@ -35,6 +36,9 @@ __device__ __forceinline__ void kr_stream_rows(const double2 *__restrict__ Hpack
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) { ar[q][o] = 0; br[q][o] = 0; ai[q][o] = 0; bi[q][o] = 0; }
     constexpr int UNR = 4;
+    // (not unrolled: hipcc otherwise issues the loads of ALL chunks of the pass up front -- 96 x 16 bytes per thread at NP = 128 --
+    //  and spills 1-2.5 KB per thread: 600 us per step at K = 256 against 21 us with one chunk in flight; round 3)
+#pragma unroll 1
     for (int j0 = 0; j0 < JS; j0 += UNR) {
         double2 h[LMAX + 1][UNR];
 #pragma unroll
@@ -42,7 +46,16 @@ __device__ __forceinline__ void kr_stream_rows(const double2 *__restrict__ Hpack
 #pragma unroll
             for (int m = 0; m <= LMAX; ++m) {
                 h[m][u] = make_double2(0.0, 0.0);
-                if (m <= L) h[m][u] = Hpack[((size_t)m * JS + j0 + u) * RT + tt];
+                if (m <= L) {
+                    // buffer load: resource (SGPRs) + one per-lane byte offset + a scalar offset per element.  With global
+                    // addressing hipcc hoists the 64-bit address of every load of the unrolled pass out of the step loop
+                    // (NP = 128: 96 addresses, 1.8-2.5 KB of scratch per thread: 600 us per step at K = 256; round 3)
+                    const unsigned soff = (unsigned)((((unsigned)m * JS + (unsigned)(j0 + u)) * RT) * 16u);
+                    const kr_su4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tt * 16, soff, 0);
+                    double2 d;
+                    __builtin_memcpy(&d, &raw, 16);
+                    h[m][u] = d;
+                }
             }
         }
 #pragma unroll
@@ -90,6 +103,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
     const double my_thr = kr_load_my_thr(a);
     const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x] : 0);
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gx.Hpack, 0, (int)(a.pack_stride * 16), 0x00020000);
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
@@ -129,7 +143,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
 #pragma unroll
                 for (int q = 0; q < KT; ++q) xp[q] = (j == m) ? &sx[cur][q][xoff] : &sy[w ^ 1][q][xoff];
                 double sr[KT][1], si[KT][1];
-                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(gx.Hpack, tt, L, e, xp, sr, si);
+                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(hrsrc, tt, L, e, xp, sr, si);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     const double yr = fma(f, si[q][0], pr[q]);
@@ -173,6 +187,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
     const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
     const double my_thr = kr_load_my_thr(a);
     const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[blockIdx.x] : 0);
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gx.Hpack, 0, (int)(a.pack_stride * 16), 0x00020000);
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
@@ -206,7 +221,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
 #pragma unroll
         for (int q = 0; q < KT; ++q) xp[q] = &sx[cur][q][xoff];
         double orr[KT][1 + LMAX], oi[KT][1 + LMAX];
-        kr_stream_rows<JS, JQ, RT, LMAX, KT, 1 + LMAX>(gx.Hpack, tt, L, eg, xp, orr, oi);
+        kr_stream_rows<JS, JQ, RT, LMAX, KT, 1 + LMAX>(hrsrc, tt, L, eg, xp, orr, oi);
         double part[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
@@ -263,7 +278,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
 #pragma unroll
                 for (int q = 0; q < KT; ++q) xp[q] = &sy[w ^ 1][q][xoff];
                 double sr[KT][1], si[KT][1];
-                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(gx.Hpack, tt, L, e, xp, sr, si);
+                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(hrsrc, tt, L, e, xp, sr, si);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     yr[q] = fma(f, si[q][0], vr[q]);
@@ -288,7 +303,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
 #pragma unroll
                 for (int q = 0; q < KT; ++q) xp[q] = (j == m) ? &sx[cur][q][xoff] : &sy[w ^ 1][q][xoff];
                 double sr[KT][1], si[KT][1];
-                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(gx.Hpack, tt, L, e, xp, sr, si);
+                kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(hrsrc, tt, L, e, xp, sr, si);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
                     const double y_r = fma(f, si[q][0], pr[q]);
