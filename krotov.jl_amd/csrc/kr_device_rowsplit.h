@@ -33,7 +33,10 @@ struct KrGeomR {
     static constexpr int JSR = (JS > 16) ? 16 : JS;
     static constexpr int JSL = JS - JSR;
     static constexpr int CHUNK = (JS >= 16) ? 4 : ((JS >= 8) ? 8 : JS);  // columns per streamed chunk (register budget: the H(eps) block takes 4*JS VGPRs)
-    static_assert(NR == 8 || NR == 16 || NR == 32 || NR == 64, "NR in {8,16,32,64}");
+    // NR = NP = 128 (round 3): R = 1, the whole trajectory in ONE workgroup -- no all-gather, but the same resident H(eps) (half of it
+    // in LDS, as at NR = 64 / NP = 256) and the same one or two streamed passes per STEP instead of the streamed-generator kernels'
+    // (1 + L) matrices per ROUND: N = 128 with 129..256 trajectories
+    static_assert(NR == 8 || NR == 16 || NR == 32 || NR == 64 || (NR == 128 && NP == 128), "NR in {8,16,32,64} (128 at NP = 128)");
     static_assert(NP == 128 || NP == 256, "NP in {128,256}");
     static_assert(JS >= 2, "at least two columns per thread");
 };
@@ -43,7 +46,7 @@ template <int JQ>
 __device__ __forceinline__ double kr_row_sum_wide(double v) {
     v += kr_dpp_mov<0xB1>(v);
     v += kr_dpp_mov<0x4E>(v);
-    v += kr_dpp_mov<0x141>(v);              // 8 lanes
+    if (JQ >= 8) v += kr_dpp_mov<0x141>(v);   // 8 lanes
     if (JQ >= 16) v += kr_dpp_mov<0x140>(v);  // row_mirror: 16 lanes
     if (JQ >= 32) v += __shfl_xor(v, 16, 64);
     if (JQ >= 64) v += __shfl_xor(v, 32, 64);
@@ -93,6 +96,7 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
         dst[e + e / JS] = make_double2(__longlong_as_double((long long)kr_slot_bits(vr, phase)), __longlong_as_double((long long)kr_slot_bits(vi, phase)));
     }
     __syncthreads();
+    if constexpr (NR == NP) { (void)sflag; (void)mb; return true; }   // R = 1: the workgroup owns every row
     if ((tid >> 6) == 1 && (tid & 63) < NR) {
         const int e = rb * NR + (tid & 63);
         const double2 v = dst[e + e / JS];
@@ -480,6 +484,7 @@ static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hi
         else kr_launch_kernel((kr_rowsplit_sweep<NP, NRv, LM, true>), grid, KrGeomR<NP, NRv, LM>::THREADS, 0, s, *a);             \
         return hipGetLastError();                                                                      \
     }
+    if constexpr (NP == 128) { KR_CASE_R(1, 128) KR_CASE_R(2, 128) }   // R = 1: one workgroup per trajectory (L <= 2: LMAX = 4 spills)
     KR_CASE_R(1, 8) KR_CASE_R(1, 16) KR_CASE_R(1, 32) KR_CASE_R(1, 64)   // one control: C5's shape
     KR_CASE_R(2, 8) KR_CASE_R(2, 16) KR_CASE_R(2, 32) KR_CASE_R(2, 64)
     KR_CASE_R(4, 8) KR_CASE_R(4, 16) KR_CASE_R(4, 32) KR_CASE_R(4, 64)

@@ -472,6 +472,10 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
     if (NP > 64 && env_int("KROTOV_HIP_ROWSPLIT", 1) != 0) {
         // R workgroups per trajectory, NR = NP / R rows each (8 <= NR <= 64: the H(eps) block must fit the registers)
         int R = NP / 64;
+        // N <= 128 with more trajectories than half the CUs: R = 1, one workgroup per trajectory with the resident H(eps) block
+        // (round 3; before: the streamed-generator kernels, (1 + L) matrices per ROUND -- 39 us per step against ~10)
+        // (L <= 2: the four-control instantiation spills 2 KB per thread and loses to the streamed-generator kernels)
+        if (NP == 128 && c.L <= 2 && (long long)c.K * R > maxwg && c.K <= maxwg && env_int("KROTOV_HIP_RS_R1", 1) != 0) R = 1;
         if ((long long)c.K * R <= maxwg && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
             while (NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
             h->rowsplit = true;

@@ -247,6 +247,20 @@ def test_large_state_dimension(oracle_c, monkeypatch, rowsplit):
     assert info["NP"] == 256
 
 
+@pytest.mark.parametrize("N,NT,K,L", [(100, 4, 130, 2), (128, 3, 256, 1), (72, 3, 200, 2)])
+def test_one_workgroup_per_trajectory_with_resident_generator(oracle_c, N, NT, K, L):
+    """64 < N <= 128 with more trajectories than HALF the CUs (round 3): the row-split kernels with R = 1 -- one workgroup per
+    trajectory, H(eps) resident, generator blocks streamed per STEP -- instead of the streamed-generator kernels (per ROUND).
+    Same sweeps (/root/reference/src/optimize.jl:247-265, 303-317, 321-370) against the oracle; L >= 3 stays with the streamed
+    kernels (the four-control instantiation spills)."""
+    p = wl.dense_problem(N, NT, K, L, 4400 + N + K, 0.05, 2.0)
+    info = _run_case(oracle_c, p, check_storage=False)
+    assert info["NP"] == 128 and info["rowsplit_R"] == 1 and info["workgroups"] == K, info
+    p3 = wl.dense_problem(100, 3, 140, 3, 4501, 0.05, 2.0)
+    with kr.HipEngine(p3["H0"], p3["Hc"], p3["tlist"], 140) as eng:
+        assert eng.info()["rowsplit_R"] == 0     # three controls: streamed-generator kernels
+
+
 def test_rowsplit_with_substeps_and_generators(oracle_c):
     """Row-split kernels with ||H dt|| > 1 (sub-stepping: every sub-step gathers) and G > 1."""
     p = wl.dense_problem(96, 4, 3, 1, 47, 0.1, 50.0)
