@@ -1032,7 +1032,8 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     h->mail_words = KR_MAIL_XTAB_OFF + KR_MAIL_XTAB_WORDS;  // 2 buffers x 8 replicas (one per XCD) x 64 KB (kr_exchange); tail: a poll pass
                                                             // reads whole 64-slot chunks (kr_poll_pass); then the XCC-id table of the
                                                             // one-XCD placement (kr_sweep_update)
-    if ((size_t)h->P * 4 > KR_MAIL_RSTRIDE) { fail(h, KR_ERR_UNSUPPORTED, "%d workgroups do not fit one mailbox replica", h->P); return bail(KR_ERR_UNSUPPORTED); }
+    // (the generic update kernels do not use this mailbox: any number of tiles -- N = 8, K = 8193 used to fail here)
+    if (!h->gen_update && (size_t)h->P * 4 > KR_MAIL_RSTRIDE) { fail(h, KR_ERR_UNSUPPORTED, "%d workgroups do not fit one mailbox replica", h->P); return bail(KR_ERR_UNSUPPORTED); }
     CHK(alloc_mailbox(h, &h->mail_d, h->mail_words, h->P));
     CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
     CHK(dalloc(&h->debug_d, 8 + 8 * 1024));   // 8 phase stamps + per-workgroup arrival stamps of diagnostic builds (KR_ARRIVALS)

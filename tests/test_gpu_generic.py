@@ -70,6 +70,8 @@ def test_beyond_the_capacity_of_the_persistent_kernels(oracle_c):
     assert info["generic_update"] == 0 and info["traj_per_wg"] == 8      # round 3: two tile sets per workgroup, still persistent
     info = _check(oracle_c, wl.dense_problem(64, 3, 4200, 2, 314, 0.05, 5.0), check_storage=False)   # past 16 trajectories per CU
     assert info["generic_update"] == 1 and info["K_padded"] >= 4200
+    info = _check(oracle_c, wl.dense_problem(8, 3, 8200, 1, 315, 0.05, 1.0), check_storage=False)   # > 2048 generic tiles (round 3: kr_create
+    assert info["generic_update"] == 1 and info["K_padded"] >= 8200                               #  sized them against the persistent mailbox)
 
 
 def test_generic_with_generators_and_masks(oracle_c, monkeypatch):
