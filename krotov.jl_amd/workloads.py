@@ -131,6 +131,9 @@ def config(name):
     if name.startswith("D:"):   # ad-hoc dense problem for the developer tools: "D:N,NT,K,L"
         N, NT, K, L = (int(x) for x in name[2:].split(","))
         return dense_problem(N, NT, K, L, 7000 + N, 0.05, 5.0)
+    if name.startswith("L:"):   # ad-hoc open system for the developer tools: "L:levels,NT,K" (N = levels^2, one control)
+        n, NT, K = (int(x) for x in name[2:].split(","))
+        return liouvillian_problem(n_levels=n, NT=NT, K=K, seed=9000 + n)
     raise KeyError(name)
 
 
