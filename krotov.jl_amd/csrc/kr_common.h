@@ -54,6 +54,8 @@ struct KrSweepArgs {
     unsigned long long *peer_xmail[8]; // every rank's xmail (peer_xmail[rank] == xmail)
     double2 *U;              // [NT][NP*NP] precomputed step propagators, thread-major (kr_device_prop.h), or nullptr
     unsigned long long *gmail; // row-split kernels: per-trajectory vector mailbox [tiles][2][NP][4] granules
+    int rs_sets;               // row-split PAIR mode: pairs a group of workgroups carries in turn (1: one pair per group)
+    double2 *rs_scratch;       // ... and the per-workgroup scratch of their state vectors [P][KR_PAIR_MAX_SETS][2][NP] (rs_sets > 1)
     unsigned epoch_base2;    // tag base of the vector mailbox for this launch
     unsigned *status;        // [KR_STATUS_WORDS]
     unsigned long long *debug; // nullptr, or [8]: workgroup 0's cycle counts per phase (diagnostics only)

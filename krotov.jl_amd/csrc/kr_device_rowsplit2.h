@@ -208,7 +208,14 @@ __device__ __forceinline__ void kr_pair_row_dot(const double (&Er)[JS], const do
 // UPDATE = false: known-pulse sweep (dir = +1 forward, -1 backward through the adjoint pack); true: update sweep.
 // Grid: P = (K / 2) * R workgroups of 512 threads; workgroup -> (pair `tile`, row block rb) as in kr_rowsplit_sweep.
 // =============================================================================================
-template <int NP, int NR, bool UPDATE>
+// MULTI (round 3): more pairs than groups -- every group of R workgroups carries a.rs_sets pairs in turn (pair s * tiles + tile in
+// set s).  The blocks of H(eps) and H_1 are resident once and serve every set (shared generator).  Known-pulse sweeps: the sets are
+// independent, one whole sweep after the other.  Update sweep: per step, phase A of every set (partial sums accumulate), ONE
+// exchange, then the rounds of every set; between its turns a set keeps psi(t_n) (the all-gathered vectors) in a per-workgroup
+// global scratch and the phase-A products of its rows in LDS.  N = 256 with 65..256 trajectories: ~S x the C5 step instead of
+// the streamed-generator kernels (8 x).  MULTI = false is the kernel of C5, unchanged.
+#define KR_PAIR_MAX_SETS 4
+template <int NP, int NR, bool UPDATE, bool MULTI = false>
 __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepArgs a) {
     using G = KrGeomR<NP, NR, 1>;
     constexpr int JS = G::JS, JQ = G::JQ, R = G::R, T = G::THREADS, KP = 2;
@@ -226,6 +233,9 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
     __shared__ double stot[2 + 1];
     __shared__ int sflag[2];
     __shared__ int salive;
+    __shared__ double sab[MULTI ? KR_PAIR_MAX_SETS : 1][KP][4][MULTI ? NR : 1];   // phase-A products b, a_1 of the rows, per set (update sweep)
+    __shared__ unsigned scnt[MULTI ? KR_PAIR_MAX_SETS : 1][KP];                  // all-gather counters of the sets' trajectories
+    const int S = MULTI ? a.rs_sets : 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = a.P / R;   // pairs
@@ -242,6 +252,9 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
     const size_t slab = (size_t)a.Kp * N;
     size_t kbase[KP];
     kbase[0] = (size_t)(2 * tile) * N; kbase[1] = (size_t)(2 * tile + 1) * N;
+    // per-workgroup scratch of the sets' state vectors (MULTI): [wg][set][q][NP]
+    double2 *vscr = nullptr;
+    if constexpr (MULTI) vscr = a.rs_scratch + (size_t)wg * KR_PAIR_MAX_SETS * KP * NP;
 
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gx.Hpack, 0, (int)(a.pack_stride * 16), 0x00020000);
     KrPairBox box[KP];
@@ -252,9 +265,20 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
         box[q].counter = 0;
         box[q].local = false;
     }
+    // set s of this group: pair s * tiles + tile
+    auto select_set = [&](const int s) {
+        if constexpr (MULTI) {
+#pragma unroll
+            for (int q = 0; q < KP; ++q) {
+                const size_t traj = (size_t)2 * ((size_t)s * tiles + tile) + q;
+                kbase[q] = traj * N;
+                box[q].base = a.gmail + traj * 2 * NP * 4;
+            }
+        }
+    };
     if (a.xcd_group) {
         // every workgroup posts {launch tag | XCC id}; wave 0 reads its R group members: local iff all ids agree
-        unsigned long long *xtab = a.gmail + (size_t)tiles * KP * 2 * NP * 4;
+        unsigned long long *xtab = a.gmail + (size_t)tiles * S * KP * 2 * NP * 4;
         if (tid < 64) {
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -277,21 +301,29 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
 
     // full initial vectors into LDS, own elements into registers
     double pr[KP], pim[KP], cr[KP], ci[KP];
+    auto init_set = [&]() {
 #pragma unroll
-    for (int q = 0; q < KP; ++q) {
-        for (int e = tid; e < NP; e += T) {
-            double2 v = make_double2(0.0, 0.0);
-            if (e < N) v = a.init[kbase[q] + e];
-            sx[q][0][e] = v;
+        for (int q = 0; q < KP; ++q) {
+            for (int e = tid; e < NP; e += T) {
+                double2 v = make_double2(0.0, 0.0);
+                if (e < N) v = a.init[kbase[q] + e];
+                sx[q][0][e] = v;
+            }
+            pr[q] = 0.0; pim[q] = 0.0; cr[q] = 0.0; ci[q] = 0.0;
+            if (row_ok) {
+                const double2 v = a.init[kbase[q] + row];
+                pr[q] = v.x; pim[q] = v.y;
+                if (UPDATE) { const double2 c = a.X[kbase[q] + row]; cr[q] = c.x; ci[q] = c.y; }
+                if (a.store && owner) a.store[(size_t)((a.dir > 0) ? 0 : NT) * slab + kbase[q] + row] = v;
+            }
         }
-        pr[q] = 0.0; pim[q] = 0.0; cr[q] = 0.0; ci[q] = 0.0;
-        if (row_ok) {
-            const double2 v = a.init[kbase[q] + row];
-            pr[q] = v.x; pim[q] = v.y;
-            if (UPDATE) { const double2 c = a.X[kbase[q] + row]; cr[q] = c.x; ci[q] = c.y; }
-            if (a.store && owner) a.store[(size_t)((a.dir > 0) ? 0 : NT) * slab + kbase[q] + row] = v;
-        }
+    };
+    if constexpr (!(MULTI && UPDATE)) init_set();   // (update sweep with sets: every set loads its vectors at its turn, step 0 from a.init)
+    else {
+#pragma unroll
+        for (int q = 0; q < KP; ++q) { pr[q] = 0.0; pim[q] = 0.0; cr[q] = 0.0; ci[q] = 0.0; }
     }
+    if constexpr (MULTI) { if (tid < KR_PAIR_MAX_SETS * KP) scnt[tid / KP][tid % KP] = 0u; }
     // the control block H_1, resident for the whole sweep (registers + LDS); the H(eps) block: Er / Ei
     double Er[JS], Ei[JS], H1r[JSH], H1i[JSH];
 #pragma unroll
@@ -349,6 +381,15 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
         __syncthreads();                                                                                                 \
     }
 
+    const int KS = (MULTI && !UPDATE) ? S : 1;   // known-pulse sweeps: one whole sweep per set
+    for (int kset = 0; kset < KS; ++kset) {
+    if constexpr (MULTI && !UPDATE) if (kset > 0) {
+        __syncthreads();
+        select_set(kset);
+        box[0].counter = 0; box[1].counter = 0;   // (every trajectory has its own mailbox)
+        init_set();
+        __syncthreads();
+    }
     double ecur = 0.0;
     int cur = 0;
     for (int step = 0; step < NT; ++step) {
@@ -379,6 +420,29 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
             // phase A for both trajectories: b = H(eps_g) psi and a_1 = H_1 psi for the own rows, one pass over x each
             double part[2], du[2];
             part[0] = 0.0; part[1] = 0.0;
+            for (int as = 0; as < S; ++as) {
+            if constexpr (MULTI) {
+                // set `as` takes its turn: state vectors from the scratch (step 0: the initial states), chi(t_n) of the own rows
+                select_set(as);
+                __syncthreads();   // the previous set's row-dots have read sx
+                const int q = tid >> 8, e = tid & 255;   // 512 threads: one element of one trajectory each (NP = 256; NP = 128: half idle)
+                if (e < NP) {
+                    double2 v = make_double2(0.0, 0.0);
+                    if (step == 0) { if (e < N) v = a.init[kbase[q] + e]; }
+                    else v = vscr[((size_t)as * KP + q) * NP + e];
+                    sx[q][cur][e] = v;
+                }
+#pragma unroll
+                for (int q2 = 0; q2 < KP; ++q2) {
+                    cr[q2] = 0.0; ci[q2] = 0.0;
+                    if (row_ok) {
+                        const double2 c = a.X[(size_t)n * slab + kbase[q2] + row];
+                        cr[q2] = c.x; ci[q2] = c.y;
+                        if (step == 0 && a.store && owner) a.store[kbase[q2] + row] = a.init[kbase[q2] + row];
+                    }
+                }
+                __syncthreads();
+            }
 #pragma unroll
             for (int q = 0; q < KP; ++q) {
                 {   // ONE pass over the x slice for both blocks, four columns at a time
@@ -403,8 +467,10 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
                     a1r[q] = kr_row_sum_wide<JQ>(aa[1] - bb[1]); a1i[q] = kr_row_sum_wide<JQ>(cc[1] + dd[1]);
                 }
                 if ((gx.present & 1u)) part[0] += cr[q] * a1i[q] - ci[q] * a1r[q];
-                if (n + 1 < NT && row_ok) { const double2 c = a.X[(size_t)(n + 1) * slab + kbase[q] + row]; cr[q] = c.x; ci[q] = c.y; }
+                if (!MULTI && n + 1 < NT && row_ok) { const double2 c = a.X[(size_t)(n + 1) * slab + kbase[q] + row]; cr[q] = c.x; ci[q] = c.y; }
+                if constexpr (MULTI) if (owner) { sab[as][q][0][il] = br[q]; sab[as][q][1][il] = bi[q]; sab[as][q][2][il] = a1r[q]; sab[as][q][3][il] = a1i[q]; }
             }
+            }   // sets
             KR_STAMP(tS)
             if (!kr_exchange<2, NR, KR_RS_SCHED>(a, n, wg, owner, il, part, du, spart, stot)) return;
             KR_STAMP(tX)
@@ -425,6 +491,22 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
         kr_plan_fast(a, my_thr, theta, s, m);
         const double fs = (s == 1) ? sdt : sdt / (double)s;
 
+        for (int bs = 0; bs < ((MULTI && UPDATE) ? S : 1); ++bs) {
+        if constexpr (MULTI && UPDATE) {
+            // set `bs` takes its turn: its rows' phase-A products from LDS, psi(t_n) of the own rows from the scratch (it is needed
+            // last -- psi + y_1 --, so the load's latency hides behind the rounds), the all-gather counters of its trajectories
+            select_set(bs);
+#pragma unroll
+            for (int q = 0; q < KP; ++q) {
+                box[q].counter = scnt[bs][q];
+                br[q] = sab[bs][q][0][il]; bi[q] = sab[bs][q][1][il]; a1r[q] = sab[bs][q][2][il]; a1i[q] = sab[bs][q][3][il];
+                pr[q] = 0.0; pim[q] = 0.0;
+                if (row_ok) {
+                    const double2 v = (step == 0) ? a.init[kbase[q] + row] : vscr[((size_t)bs * KP + q) * NP + row];
+                    pr[q] = v.x; pim[q] = v.y;
+                }
+            }
+        }
         for (int sub = 0; sub < s; ++sub) {
             // Horner as in kr_rowsplit_sweep, the two trajectories alternating: with the phase-A products known (update sweep, first
             // sub-step) the constant is v = -i fs H psi and the result psi + y_1; otherwise x0 = psi and the result is y_0.
@@ -506,6 +588,18 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
 #pragma unroll
             for (int q = 0; q < KP; ++q) a.store[(size_t)slot * slab + kbase[q] + row] = make_double2(pr[q], pim[q]);
         }
+        if constexpr (MULTI && UPDATE) {
+            // the set's turn ends: psi(t_{n+1}) -- complete in every workgroup of the group -- goes to this workgroup's scratch
+            const int q = tid >> 8, e = tid & 255;
+            if (e < NP) vscr[((size_t)bs * KP + q) * NP + e] = sx[q][cur][e];
+            if (tid < KP) scnt[bs][tid] = box[tid].counter;
+            if (step == NT - 1 && a.fin && owner && row_ok) {
+#pragma unroll
+                for (int q2 = 0; q2 < KP; ++q2) a.fin[kbase[q2] + row] = make_double2(pr[q2], pim[q2]);
+            }
+            __syncthreads();   // (scratch stores are this workgroup's own: visible to its later loads; the barrier orders the LDS counters)
+        }
+        }   // sets
     }
     if (stamp && tid == 0) { a.debug[0] = tS; a.debug[1] = tD; a.debug[2] = tG; a.debug[3] = tX; a.debug[7] = nG; a.debug[5] = dbg_tpoll; a.debug[6] = dbg_npass;
 #ifdef KR_PAIR_PROBE
@@ -517,9 +611,10 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
 #undef KR_PAIR_COLLECT
 #undef KR_H1R
 #undef KR_H1I
-    if (a.fin && owner && row_ok) {
+    if constexpr (!(MULTI && UPDATE)) if (a.fin && owner && row_ok) {
 #pragma unroll
         for (int q = 0; q < KP; ++q) a.fin[kbase[q] + row] = make_double2(pr[q], pim[q]);
     }
+    }   // known-pulse sets
     if (UPDATE && wg == 0 && tid == 0) a.g_a_int[0] = gint;
 }

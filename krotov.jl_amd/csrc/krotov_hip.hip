@@ -48,6 +48,8 @@ struct kr_handle {
     kr_launch_fn launch = nullptr;
     // row-split mode (64 < N <= 256): R workgroups of 512 threads share one trajectory (kr_device_rowsplit.h)
     bool rowsplit = false;
+    int rs_sets = 1;           // pair mode: pairs per group of workgroups, in turn (kr_rowsplit_pair_sweep<.., MULTI>)
+    double2 *rs_scratch_d = nullptr;
     bool rs_pair = false;      // row-split PAIR mode (kr_device_rowsplit2.h): R workgroups share two trajectories and interleave them
     int R = 1, NR = 0;
     kr_launch_fn launch_rs = nullptr;
@@ -472,11 +474,20 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
     if (NP > 64 && env_int("KROTOV_HIP_ROWSPLIT", 1) != 0) {
         // R workgroups per trajectory, NR = NP / R rows each (8 <= NR <= 64: the H(eps) block must fit the registers)
         int R = NP / 64;
+        // N = 256, one control, shared generator, more pairs than groups of 8 workgroups: the groups carry up to 4 pairs each in turn
+        // (round 3: kr_rowsplit_pair_sweep<.., MULTI>; before: the streamed-generator kernels, 8 x the time per trajectory)
+        int rs_sets = 1;
+        if (NP == 256 && c.L == 1 && h->G == 1 && env_int("KROTOV_HIP_RS_LMAX1", 1) != 0 && env_int("KROTOV_HIP_RS_PAIR", 1) != 0 &&
+            env_int("KROTOV_HIP_RS_SETS", 1) != 0 && maxwg >= 8 && (long long)c.K * R > maxwg) {
+            const int groups = maxwg / 8, pairs = (c.K + 1) / 2;
+            const int need = (pairs + groups - 1) / groups;
+            if (need >= 2 && need <= 4) rs_sets = need;
+        }
         // N <= 128 with more trajectories than half the CUs: R = 1, one workgroup per trajectory with the resident H(eps) block
         // (round 3; before: the streamed-generator kernels, (1 + L) matrices per ROUND -- 39 us per step against ~10)
         // (L <= 2: the four-control instantiation spills 2 KB per thread and loses to the streamed-generator kernels)
         if (NP == 128 && c.L <= 2 && (long long)c.K * R > maxwg && c.K <= maxwg && env_int("KROTOV_HIP_RS_R1", 1) != 0) R = 1;
-        if ((long long)c.K * R <= maxwg && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
+        if (((long long)c.K * R <= maxwg || rs_sets > 1) && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
             while (NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
             h->rowsplit = true;
             if (c.L == 1 && env_int("KROTOV_HIP_RS_LMAX1", 1) != 0) h->LMAXv = 1;   // row-split kernels have an instantiation for ONE control (C5): fewer
@@ -486,11 +497,12 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             // all-gather), the same workgroups in groups of 2R carry TWO trajectories with 32 rows each: both blocks resident,
             // one trajectory's all-gather behind the other's row-dot.  One control, shared generator (C5's shape); an odd K is
             // padded with one zero trajectory (it contributes nothing to any sum).  KROTOV_HIP_RS_PAIR=0 keeps the single mode.
-            if (NP / R == 64 && h->LMAXv == 1 && h->G == 1 && c.K >= 2 && (long long)((c.K + 1) / 2) * (2 * R) <= maxwg &&
+            if (NP / R == 64 && h->LMAXv == 1 && h->G == 1 && c.K >= 2 && ((long long)((c.K + 1) / 2) * (2 * R) <= maxwg || rs_sets > 1) &&
                 env_int("KROTOV_HIP_RS_PAIR", 1) != 0) {
                 h->rs_pair = true;
                 R *= 2;
             }
+            h->rs_sets = h->rs_pair ? rs_sets : 1;
             h->R = R;
             h->NR = NP / R;
             h->threads = 512;  // mirrors KrGeomR
@@ -503,6 +515,11 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             h->KTILE = h->KT;
             h->Kp = ((c.K + h->KT - 1) / h->KT) * h->KT;   // pair mode: padded to an even count
             h->P = (h->Kp / h->KT) * R;
+            if (h->rs_sets > 1) {   // groups x sets pairs, zero trajectories behind the last real one
+                const int groups = maxwg / R;
+                h->Kp = 2 * groups * h->rs_sets;
+                h->P = groups * R;
+            }
             h->perm.assign(c.K, 0);
             wg_gen.assign(h->Kp / h->KT, 0);
             for (int k = 0; k < c.K; ++k) { h->perm[k] = k; wg_gen[k / h->KT] = tg ? tg[k] : 0; }
@@ -741,7 +758,7 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d,
-                    h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d};
+                    h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected && !h->peers_in_process)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -997,6 +1014,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         h->xcd_group = ((h->Kp / h->KT) % 8 == 0) && env_int("KROTOV_HIP_XCD_GROUP", 1) != 0;   // (tiles % 8: pairs in pair mode)
         CHK(dalloc(&h->gmail_d, h->gmail_words));
         CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
+        if (h->rs_sets > 1) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * 4 /* KR_PAIR_MAX_SETS */ * 2 * NP));
     }
     std::vector<double> dt(NT);
     for (int n = 0; n < NT; ++n) dt[n] = cfg->tlist[n + 1] - cfg->tlist[n];
@@ -1213,6 +1231,8 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.use_mfma = h->use_mfma ? (1 | (env_int("KROTOV_HIP_EXPM_PS", 1) != 0 ? 2 : 0)) : 0;   // bit 1: Paterson-Stockmeyer form of the matrix-core propagator build
     a.gmail = h->gmail_d;
     a.xcd_group = h->xcd_group ? 1 : 0;
+    a.rs_sets = h->rs_sets;
+    a.rs_scratch = h->rs_scratch_d;
     a.pack_stride = h->pack_stride;
     a.Hdense = h->Hdense_fw;
     a.dense_stride = h->dense_stride;

@@ -236,11 +236,13 @@ def test_large_state_dimension(oracle_c, monkeypatch, rowsplit):
     kernels (kr_device_stream.h)."""
     monkeypatch.setenv("KROTOV_HIP_ROWSPLIT", rowsplit)
     for (N, NT, K, L, seed) in [(65, 6, 2, 1, 41), (100, 5, 3, 2, 42), (128, 4, 2, 1, 43), (200, 3, 2, 3, 44),
-                                (130, 3, 40, 1, 45), (256, 3, 60, 2, 46), (256, 2, 70, 1, 48)]:
+                                (130, 3, 40, 1, 45), (256, 3, 60, 2, 46), (256, 2, 70, 1, 48), (200, 2, 70, 2, 49)]:
         p = wl.dense_problem(N, NT, K, L, seed, 0.05, 2.0)
         info = _run_case(oracle_c, p, check_storage=(K < 10))
         assert info["NP"] in (128, 256)
-        fits = K * (info["NP"] // 64) <= 256   # K = 70 at NP = 256 needs 280 workgroups: streamed kernels take over
+        # K = 70 at NP = 256 needs 280 workgroups: with two controls the streamed kernels take over, with ONE control the
+        # pair-mode groups carry two pairs each in turn (round 3)
+        fits = K * (info["NP"] // 64) <= 256 or (info["NP"] == 256 and L == 1 and K <= 256)
         assert (info["rowsplit_R"] > 0) == (rowsplit == "1" and fits)
     p = wl.liouvillian_problem(n_levels=16, NT=4, K=3, seed=256001)   # C5's operators, short grid
     info = _run_case(oracle_c, p)
@@ -259,6 +261,18 @@ def test_one_workgroup_per_trajectory_with_resident_generator(oracle_c, N, NT, K
     p3 = wl.dense_problem(100, 3, 140, 3, 4501, 0.05, 2.0)
     with kr.HipEngine(p3["H0"], p3["Hc"], p3["tlist"], 140) as eng:
         assert eng.info()["rowsplit_R"] == 0     # three controls: streamed-generator kernels
+
+
+@pytest.mark.parametrize("levels,NT,K,sets", [(12, 3, 70, 2), (12, 2, 140, 3), (16, 2, 250, 4)])
+def test_pair_mode_with_several_pairs_per_group(oracle_c, levels, NT, K, sets):
+    """128 < N <= 256, one control, shared generator and more pairs than groups of 8 workgroups (round 3): every group carries
+    2..4 pairs in turn (kr_rowsplit_pair_sweep<.., MULTI>) -- known-pulse sweeps set after set, update sweep with ONE exchange per
+    step over all sets (/root/reference/src/optimize.jl:339-349 sums over ALL trajectories) -- instead of the streamed-generator
+    kernels.  Open-system generators (C5's construction, /root/reference/src/workspace.jl:69,149-161: true adjoint backwards)."""
+    p = wl.liouvillian_problem(n_levels=levels, NT=NT, K=K, seed=9100 + K)
+    info = _run_case(oracle_c, p, check_storage=False)
+    assert info["NP"] == 256 and info["rowsplit_R"] == 8 and info["KT"] == 2 and info["workgroups"] == 256, info
+    assert info["K_padded"] == 64 * sets, info
 
 
 def test_rowsplit_with_substeps_and_generators(oracle_c):
