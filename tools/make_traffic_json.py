@@ -28,7 +28,7 @@ for cfg, (N, NT, K) in shapes.items():
         m = re.match(r"(?:void )?(\S.*?)\s+launches=(\d+) raw_per_launch=([\d.]+)", line)
         if sect and m and dominant[cfg] in m.group(1):
             name, n, v = m.group(1).strip(), int(m.group(2)), float(m.group(3))
-            if cfg == "C5" and "true>" not in name:     # <.., UPDATE = true>: the update sweep, not the known-pulse sweeps
+            if cfg == "C5" and ", true" not in name:     # <.., UPDATE = true[, MULTI]>: the update sweep, not the known-pulse sweeps
                 continue
             # the caller's launches only: the CAL = 1 instantiations are kr_create's short calibration sweeps
             if re.search(r"<[^>]*>", name) and cfg in ("C3", "C4"):
