@@ -382,7 +382,9 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
     }
 
     const int KS = (MULTI && !UPDATE) ? S : 1;   // known-pulse sweeps: one whole sweep per set
-    for (int kset = 0; kset < KS; ++kset) {
+    int kset = 0;
+kr_next_set:
+    {
     if constexpr (MULTI && !UPDATE) if (kset > 0) {
         __syncthreads();
         select_set(kset);
@@ -616,5 +618,7 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
         for (int q = 0; q < KP; ++q) a.fin[kbase[q] + row] = make_double2(pr[q], pim[q]);
     }
     }   // known-pulse sets
+    if constexpr (MULTI && !UPDATE) { if (++kset < KS) goto kr_next_set; }
+    (void)kset; (void)KS;
     if (UPDATE && wg == 0 && tid == 0) a.g_a_int[0] = gint;
 }
