@@ -348,3 +348,67 @@ def test_propagator_build_paterson_stockmeyer_agrees_with_horner_and_oracle(monk
             assert np.max(np.abs(a - b)) < 5e-14
         psi_ref, _ = o.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False)
         assert np.max(np.abs(out["1"][0] - psi_ref)) < 1e-11
+
+
+def _serial_iteration(o, H0, Hc, present, tg, tl, eps, S, lam, psi0, tgt):
+    """optimize.jl:303-370 restated serially on the oracle's exact step propagator, with per-trajectory generators (tg) and
+    control_derivs === nothing where present[g, l] == 0 (optimize.jl:344)."""
+    G, L, NT = len(H0), eps.shape[0], eps.shape[1]
+    K, N = psi0.shape
+    U = [[o.step_propagator(H0[g], Hc[g], eps[:, n], tl[n + 1] - tl[n]) for n in range(NT)] for g in range(G)]
+    psi = psi0.copy()
+    for n in range(NT):
+        for g in range(G):
+            ks = tg == g
+            psi[ks] = psi[ks] @ U[g][n].T
+    psiT = psi.copy()
+    _, _, chiT = wl.chi_and_JT("ss", psiT, tgt)
+    X = np.empty((NT + 1, K, N), complex)
+    X[NT] = chiT
+    for n in range(NT - 1, -1, -1):
+        for g in range(G):
+            ks = tg == g
+            X[n, ks] = X[n + 1, ks] @ U[g][n].conj()
+    psi, eps_o, ga_o = psi0.copy(), eps.copy(), np.zeros(L)
+    for n in range(NT):
+        dt = tl[n + 1] - tl[n]
+        for l in range(L):
+            du = 0.0
+            for g in range(G):
+                if present[g, l]:
+                    ks = tg == g
+                    du += np.sum(np.conj(X[n, ks]) * (psi[ks] @ Hc[g, l].T)).imag
+            eps_o[l, n] = eps[l, n] + S[l, n] / lam[l] * du
+            ga_o[l] += S[l, n] / lam[l] * du * du * dt
+        for g in range(G):
+            ks = tg == g
+            psi[ks] = psi[ks] @ o.step_propagator(H0[g], Hc[g], eps_o[:, n], dt).T
+    return psiT, chiT, eps_o, ga_o, psi
+
+
+@pytest.mark.parametrize("N,K", [(64, 256), (32, 160), (16, 24)])
+def test_window_variant_with_generators_and_missing_controls(N, K):
+    """The window variant of the update kernel (all control operators Hermitian; round 3: the partial sums of step n + 1 are
+    deposited with the last barrier of step n; N = 16, K = 24: the one-XCD placement runs it with wave 1 publishing) with G = 3
+    generators of which one lacks control 1 (mu === nothing, /root/reference/src/optimize.jl:344) -- the carried c_l and the
+    deposited sums must respect the mask of each workgroup's generator.  Against the serial restatement on the oracle."""
+    import krotov_oracle as o
+    rng = np.random.default_rng(1200 + N)
+    NT, L, G = 7, 2, 3
+    tg = rng.permutation(np.arange(K) % G).astype(np.int32)
+    base = wl.dense_problem(N, NT, K, L, 930 + N, 0.05, 0.05)
+    H0 = np.array([base["H0"] * (1.0 + 0.1 * g) + 0.05 * wl.random_hermitian(rng, N) for g in range(G)])
+    Hc = np.array([[base["Hc"][l] * (1.0 - 0.07 * g) for l in range(L)] for g in range(G)])
+    present = np.ones((G, L), np.uint8)
+    present[1, 1] = 0
+    tl, eps, S, lam, psi0, tgt = base["tlist"], base["eps"], base["S"], base["lam"], base["psi0"], base["tgt"]
+    psiT_o, chiT, eps_o, ga_o, psi1_o = _serial_iteration(o, H0, Hc, present, tg, tl, eps, S, lam, psi0, tgt)
+    with kr.HipEngine(H0, Hc, tl, K, traj_generator=tg, hc_present=present) as eng:
+        info = eng.info()
+        assert info["hermitian_controls_path"] == 1 and info["generic_update"] == 0, eng.plan()
+        eng.set_initial_states(psi0)
+        psiT = eng.forward(eps)
+        assert np.max(np.abs(psiT - psiT_o)) < 1e-11
+        eps_new, ga, psiT1 = eng.iteration(eps, chiT, S, lam)
+    assert np.max(np.abs(eps_o - eps)) > 1e-6
+    assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < TOL_GA and np.max(np.abs(psiT1 - psi1_o)) < TOL_STATE
