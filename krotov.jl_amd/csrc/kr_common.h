@@ -205,6 +205,7 @@ struct KrGenArgs {
     double tol;
     double thr[KR_MAX_ORDER];
     int N, NT, Kp, L, G, KTG, RP, JQ, tiles, dir, n;
+    int fused;                 // stepped update sweep on one rank: kr_gen_form sums the partials itself, kr_gen_apply adds the next step's partial sums
     // step propagator (kr_prop_method): per-step tables of the polynomial methods (kr_gen_propagate)
     int method, ptab_stride;
     const double *ptab;

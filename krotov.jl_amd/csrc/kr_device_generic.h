@@ -224,18 +224,13 @@ __global__ __launch_bounds__(256) void kr_gen_known(const KrGenArgs a) {
     if (a.fin) for (int e = threadIdx.x; e < tot; e += blockDim.x) a.fin[tb + e] = psi[e];
 }
 
-// update sweep, step a.n: partial sums of the update integrand over this tile's trajectories
+// partial sums of the update integrand of step n over this tile's trajectories: psi(t_n) is in LDS (`psi`), chi(t_n) is fetched here
 template <int KTG>
-__global__ __launch_bounds__(256) void kr_gen_partial(const KrGenArgs a) {
-    KR_GEN_LDS(KTG)
-    __shared__ double sred[256];
-    const int tile = blockIdx.x, N = a.N, L = a.L, tot = KTG * N;
-    const int gen = a.tile_gen ? a.tile_gen[tile] : 0;
+__device__ __forceinline__ void kr_gen_partial_body(const KrGenArgs &a, const int n, const int tile, const int gen, double2 *psi, double2 *y0,
+                                                    double2 *y1, double2 *red, double *sred) {
+    const int N = a.N, L = a.L, tot = KTG * N;
     const size_t tb = (size_t)tile * KTG * N, slab = (size_t)a.Kp * N;
-    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-        psi[e] = a.state[tb + e];
-        y0[e] = a.X[(size_t)a.n * slab + tb + e];   // chi(t_n)
-    }
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) y0[e] = a.X[(size_t)n * slab + tb + e];   // chi(t_n)
     __syncthreads();
     const double one = 1.0;
     for (int l = 0; l < L; ++l) {
@@ -256,6 +251,17 @@ __global__ __launch_bounds__(256) void kr_gen_partial(const KrGenArgs a) {
         if (threadIdx.x == 0) a.partial[(size_t)tile * L + l] = sred[0];
         __syncthreads();
     }
+}
+// update sweep, step a.n: the partial sums as a kernel of their own (first step; every step when the sum crosses ranks)
+template <int KTG>
+__global__ __launch_bounds__(256) void kr_gen_partial(const KrGenArgs a) {
+    KR_GEN_LDS(KTG)
+    __shared__ double sred[256];
+    const int tile = blockIdx.x, N = a.N, tot = KTG * N;
+    const int gen = a.tile_gen ? a.tile_gen[tile] : 0;
+    const size_t tb = (size_t)tile * KTG * N;
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) psi[e] = a.state[tb + e];
+    kr_gen_partial_body<KTG>(a, a.n, tile, gen, psi, y0, y1, red, sred);
 }
 
 // du_local[l] = sum over tiles, fixed order (one workgroup)
@@ -279,6 +285,26 @@ __global__ __launch_bounds__(256) void kr_gen_reduce(const KrGenArgs a) {
 __global__ __launch_bounds__(256) void kr_gen_form(const KrGenArgs a) {
     const int N = a.N, NT = a.NT, L = a.L, n = a.n;
     const size_t nn = (size_t)N * N, idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // a.fused (one rank, device-side sum; round 3): every block sums the tiles' partials ITSELF, in the order and tree of
+    // kr_gen_reduce (bitwise the same totals in every block), instead of waiting for a kernel of one workgroup to do it --
+    // the stepped sweep is a chain of dependent launches, and this takes one of four out of every time step
+    __shared__ double sdu[32];
+    if (a.fused) {
+        __shared__ double sred[256];
+        for (int l = 0; l < L; ++l) {
+            double acc = 0.0;
+            for (int t = threadIdx.x; t < a.tiles; t += 256) acc += a.partial[(size_t)t * L + l];
+            sred[threadIdx.x] = acc;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) sred[threadIdx.x] += sred[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) sdu[l] = sred[0];
+            __syncthreads();
+        }
+        if (blockIdx.x == 0 && threadIdx.x < L) a.du_local[threadIdx.x] = sdu[threadIdx.x];
+    }
     if (idx >= nn * a.G) return;
     const int gen = (int)(idx / nn);
     const size_t e = idx % nn;
@@ -287,7 +313,8 @@ __global__ __launch_bounds__(256) void kr_gen_form(const KrGenArgs a) {
     for (int l = 0; l < L; ++l) {
         const double al = a.alpha[(size_t)l * NT + n], eg = a.eps[(size_t)l * NT + n];
         // mu_l = f_l'(eps_guess) H_l (the derivative is evaluated at the guess value, optimize.jl:337,345)
-        const double du = a.poly ? __dmul_rn(kr_gen_fprime(a, l, eg), a.du_total[l]) : a.du_total[l];
+        const double dut = a.fused ? sdu[l] : a.du_total[l];
+        const double du = a.poly ? __dmul_rn(kr_gen_fprime(a, l, eg), dut) : dut;
         const double en = __dadd_rn(eg, __dmul_rn(al, du));   // optimize.jl:355, no FMA contraction
         const double2 hl = Hb[(size_t)(1 + l) * nn + e];
         const double amp = kr_gen_f(a, l, en);
@@ -322,6 +349,13 @@ __global__ __launch_bounds__(256) void kr_gen_apply(const KrGenArgs a) {
         a.state[tb + e] = psi[e];
         if (a.store) a.store[(size_t)(n + 1) * slab + tb + e] = psi[e];
         if (a.fin && n == NT - 1) a.fin[tb + e] = psi[e];
+    }
+    // a.fused: the partial sums of step n + 1 from the state this workgroup has just produced (still in LDS): the next
+    // launch is the pulse update, not a kernel that reloads psi to do this
+    if (a.fused && n + 1 < NT) {
+        __shared__ double sred[256];
+        __syncthreads();
+        kr_gen_partial_body<KTG>(a, n + 1, tile, gen, psi, y0, y1, red, sred);
     }
 }
 #undef KR_GEN_LDS

@@ -1429,6 +1429,20 @@ static int launch_update_stepped(kr_handle *h, const double *eps_guess_dev, doub
     if (h->store_fw) HIPCHK(h, hipMemcpyAsync(h->Phi_d, h->psi0_d, slab * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->gint_d, 0, (size_t)L * sizeof(double), h->stream));
     const int form_grid = (int)(((size_t)h->G * N * N + 255) / 256);
+    // One rank (the sum stays on the device), L <= 32: TWO launches per time step instead of four -- the pulse update sums the
+    // tiles' partials itself, the forward step adds the partial sums of the next step (kr_device_generic.h; round 3).  The
+    // stepped sweep is a chain of dependent launches (a HIP graph of it replays no faster: DESIGN.md section 7).
+    if (!use_rccl && !use_cb && L <= 32 && env_int("KROTOV_HIP_GENERIC_FUSED", 1) != 0) {
+        g.n = 0;       // (step 0's partial sums: the plain kernel)
+        HIPCHK(h, kr_launch_generic(1, h->KTG, h->gen_tiles, h->gen_lds, h->stream, &g));
+        g.fused = 1;
+        for (int n = 0; n < NT; ++n) {
+            g.n = n;
+            HIPCHK(h, kr_launch_generic(3, h->KTG, form_grid, 0, h->stream, &g));
+            HIPCHK(h, kr_launch_generic(4, h->KTG, h->gen_tiles, h->gen_lds, h->stream, &g));
+        }
+        return KR_OK;
+    }
     for (int n = 0; n < NT; ++n) {
         g.n = n;
         HIPCHK(h, kr_launch_generic(1, h->KTG, h->gen_tiles, h->gen_lds, h->stream, &g));
