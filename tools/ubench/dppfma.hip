@@ -60,7 +60,7 @@ int main() {
         worst = fmax(worst, fabs(ref - ho[l]));
     }
     printf("semantics: out[lane] = sum_j x[16 (lane / 16) + j] h[lane][j], max |error| %.3e\n", worst);
-    const int iters = 4000;
+    const int iters = 400000;
     for (int waves = 1; waves <= 4; waves *= 2) {
         for (int dpp = 0; dpp < 2; ++dpp) {
             unsigned c[3];
