@@ -186,7 +186,7 @@ template <int JS, int JQ, class M = KrNoMid>
 __device__ __forceinline__ void kr_pair_row_dot(const double (&Er)[JS], const double (&Ei)[JS], const double2 *__restrict__ xp,
                                                 double &sr, double &si, M mid = M()) {
     constexpr int CH = (JS >= 8) ? 8 : JS;
-    double aa = 0, bb = 0, cc = 0, dd = 0;
+    double aa = 0, cc = 0;   // (two accumulators, the subtraction inside the FMA: two fp64 instructions less per row-dot and wave)
 #pragma unroll
     for (int j0 = 0; j0 < JS; j0 += CH) {
         if (j0 == (KR_PAIR_EARLY_AT ? CH : 0) || (JS == CH && j0 == 0)) mid();
@@ -196,12 +196,12 @@ __device__ __forceinline__ void kr_pair_row_dot(const double (&Er)[JS], const do
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const double hr = Er[j0 + u], hi = Ei[j0 + u];
-            aa = fma(hr, x[u].x, aa); bb = fma(hi, x[u].y, bb);
-            cc = fma(hr, x[u].y, cc); dd = fma(hi, x[u].x, dd);
+            aa = fma(hr, x[u].x, aa); cc = fma(hr, x[u].y, cc);
+            aa = fma(-hi, x[u].y, aa); cc = fma(hi, x[u].x, cc);
         }
     }
-    sr = kr_row_sum_wide<JQ>(aa - bb);
-    si = kr_row_sum_wide<JQ>(cc + dd);
+    sr = kr_row_sum_wide<JQ>(aa);
+    si = kr_row_sum_wide<JQ>(cc);
 }
 
 // =============================================================================================
