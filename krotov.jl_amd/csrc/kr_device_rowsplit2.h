@@ -70,6 +70,23 @@ __device__ __forceinline__ void kr_pair_publish(const KrPairBox &box, const int 
         else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pe), "v"(w) : "memory");
     }
 }
+// deposit AND publish by the row owners themselves, from registers (one barrier per phase instead of two: KR_PAIR_ONEBAR)
+template <int NP, int NR, int JS>
+__device__ __forceinline__ void kr_pair_deposit_publish(KrPairBox &box, const int rb, const bool owner, const int il, const double vr,
+                                                        const double vi, double2 *dst) {
+    ++box.counter;
+    const unsigned phase = (((box.counter - 1u) >> 1) & 1u) ^ 1u;
+    if (owner) {
+        const int e = rb * NR + il;
+        const unsigned long long br = kr_slot_bits(vr, phase), bi = kr_slot_bits(vi, phase);
+        dst[e] = make_double2(__longlong_as_double((long long)br), __longlong_as_double((long long)bi));
+        kr_v4u w;
+        w.x = (unsigned)br; w.y = (unsigned)(br >> 32); w.z = (unsigned)bi; w.w = (unsigned)(bi >> 32);
+        const unsigned long long *pe = box.base + (size_t)(box.counter & 1) * NP * 4 + 2 * e;
+        if (box.local) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(pe), "v"(w) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pe), "v"(w) : "memory");
+    }
+}
 // wave 0 only; `counter` / parity / phase are those of the box's LAST deposit.  Returns false when the bounded spin gave up.
 template <int NP, int NR, int JS>
 __device__ __forceinline__ bool kr_pair_collect(const KrSweepArgs &a, const KrPairBox &box, const int rb, double2 *dst,
@@ -353,6 +370,33 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
 #else
 #define KR_PROBE(acc)
 #endif
+#ifndef KR_PAIR_ONEBAR
+#define KR_PAIR_ONEBAR 1   // one barrier per phase: the row owners publish their elements themselves (from registers)
+#endif
+#if KR_PAIR_ONEBAR
+// One barrier per phase (end of round 3).  The first barrier of the two-barrier phase below only served wave 1, which read the deposited
+// block back from LDS to publish it; here every row owner stores its element into the mailbox itself, straight from its registers,
+// next to the LDS deposit.  Wave 0 retires its early pass and reads the landed vector's phase bits BEFORE it deposits (its own
+// publishing store is then the youngest memory operation it has in flight: nothing waits for its acknowledgement except the rare
+// fall-back poll), tests them behind the store, and the one barrier closes the phase.  C5, same box: known-pulse step 14.87 -> 13.91,
+// update step 18.98 -> 18.16 us.  (Also tried: the bits read in the row-dot's tail, in front of the lane reductions -- the early pass
+// has often not landed yet there and the wave stalls inside its row-dot: 13.9 -> 14.7, 18.2 -> 19.7 us.)
+#define KR_PAIR_PHASE(q_, vr_, vi_, dst_, ocollect_, odst_, early_)                                                      \
+    {                                                                                                                    \
+        unsigned long long tp_ = stamp ? __builtin_amdgcn_s_memtime() : 0; (void)tp_;                                    \
+        unsigned chk_[2 * (NP / 64)];                                                                                    \
+        if ((ocollect_) && (early_) && wave == 0) kr_pair_check_load<NP>(odst_, chk_);                                   \
+        kr_pair_deposit_publish<NP, NR, JS>(box[q_], rb, owner, il, vr_, vi_, dst_);                                     \
+        KR_PROBE(prA)                                                                                                    \
+        if ((ocollect_) && wave == 0) {                                                                                  \
+            KR_PROBE(prB)                                                                                                \
+            const bool got_ = (early_) && kr_pair_check_test<NP>(box[1 - (q_)], chk_);                                   \
+            KR_PROBE(prC)                                                                                                \
+            if (!got_) { if (!kr_pair_collect<NP, NR, JS>(a, box[1 - (q_)], rb, odst_, dbg_tpoll, dbg_npass) && lane == 0) salive = 0; } \
+        }                                                                                                                \
+        __syncthreads();                                                                                                 \
+    }
+#else
 #define KR_PAIR_PHASE(q_, vr_, vi_, dst_, ocollect_, odst_, early_)                                                      \
     {                                                                                                                    \
         unsigned long long tp_ = stamp ? __builtin_amdgcn_s_memtime() : 0; (void)tp_;                                    \
@@ -373,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
         }                                                                                                                \
         __syncthreads();                                                                                                 \
     }
+#endif
     // (a collect that gave up is noticed once per step, below: the status word makes every later spin of the sweep return at once)
     // Collect only (the last pending vector of a step): wave 0 polls, one barrier.
 #define KR_PAIR_COLLECT(q_, dst_)                                                                                        \
