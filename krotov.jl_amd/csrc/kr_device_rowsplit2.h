@@ -266,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
     const KrGen<1> gx = kr_gen_ctx<1>(a, a.wg_gen ? a.wg_gen[tile] : 0);
     const int xoff = jq;   // strided column map: column jj of this thread <-> element jj * JQ + jq
     const int N = a.N, NT = a.NT;
+    const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
     const size_t slab = (size_t)a.Kp * N;
     size_t kbase[KP];
     kbase[0] = (size_t)(2 * tile) * N; kbase[1] = (size_t)(2 * tile + 1) * N;
@@ -445,6 +446,8 @@ kr_next_set:
         const double sdt = (a.dir > 0) ? dtn : -dtn;
         const double eg = a.eps[n];
         double e = eg, de = 0.0;
+        // row of the step's economized polynomial (lane j: entry j), consumed behind the exchange; 0 = none, the step takes Taylor's plan
+        const double ec = econ_rows ? econ_rows[(size_t)n * KR_ECON_W] : 0.0;
         // H(eps_guess) block: rebuilt from the drift every KR_RS_REFRESH steps (one streamed pass over H0; bounds the accumulated
         // rounding), otherwise advanced in registers by (eps - ecur) H_1
         if ((step % KR_RS_REFRESH) == 0) {
@@ -536,6 +539,13 @@ kr_next_set:
         theta *= fabs(sdt);
         int s, m;
         kr_plan_fast(a, my_thr, theta, s, m);
+        // economized step polynomial (kr_device.h: KrEcon; here also for generators that are only NEARLY Hermitian -- a Liouvillian
+        // with weak dissipation: kr_econ_rows_kernel bounds the truncation on an ellipse around the numerical range)
+        int se = s, me = m;
+        KrEcon eco = kr_econ_select(ec, theta, se, me);
+        if (eco.on && (s > 1 || me < m)) { s = se; m = me; }          // (a row whose degree saves nothing is not used: the ellipse bound
+        else { eco.on = false; eco.a0 = 1.0; eco.a1 = 1.0; }          //  of a generator far from Hermitian can exceed Taylor's)
+        const double my_g = eco.on ? ec : my_rinv;   // Horner ratios of this step, lane j holds g_j
         const double fs = (s == 1) ? sdt : sdt / (double)s;
 
         for (int bs = 0; bs < ((MULTI && UPDATE) ? S : 1); ++bs) {
@@ -585,8 +595,10 @@ kr_next_set:
                 src[0] = sx[0][cur]; src[1] = sx[1][cur];
             }
             for (int j = m; j >= jlast; --j) {
-                const double f = fs * kr_rinv_lane(my_rinv, j);
                 const bool last = (j == jlast);
+                // (known-pulse form, last round: a_0 psi + a_1 z y_1 -- entry 1 of the row is a_1 itself, not a ratio; Taylor: 1, 1)
+                const bool scale0 = !have_v && last;
+                const double f = scale0 ? fs * eco.a1 : fs * kr_rinv_lane(my_g, j);
 #pragma unroll
                 for (int q = 0; q < KP; ++q) {
                     double sr, si;
@@ -596,9 +608,9 @@ kr_next_set:
                     double2 *pending = (q == 0) ? src[1] : (last ? sx[0][cur ^ 1] : sy[0][w]);   // where the other trajectory's vector lands
                     const KrPairMid<NP, NR> mid{box[1 - q].base, box[1 - q].counter, rb, pending, early && wave == 0};
                     kr_pair_row_dot<JS, JQ>(Er, Ei, src[q] + xoff, sr, si, mid);
-                    yr[q] = fma(f, si, x0r[q]);
-                    yi[q] = fma(-f, sr, x0i[q]);
-                    if (last && have_v) { yr[q] += pr[q]; yi[q] += pim[q]; }   // psi' = psi + y_1
+                    yr[q] = fma(f, si, scale0 ? eco.a0 * x0r[q] : x0r[q]);
+                    yi[q] = fma(-f, sr, scale0 ? eco.a0 * x0i[q] : x0i[q]);
+                    if (last && have_v) { yr[q] = fma(eco.a1, yr[q], eco.a0 * pr[q]); yi[q] = fma(eco.a1, yi[q], eco.a0 * pim[q]); }   // psi' = a_0 psi + a_1 y_1  (Taylor: 1, 1)
                     double2 *dst = last ? sx[q][cur ^ 1] : sy[q][w];
                     KR_STAMP(tD)
                     // deposit + publish q; meanwhile collect what the OTHER trajectory published one phase earlier:
@@ -619,7 +631,7 @@ kr_next_set:
             }
             if (have_v && m == 1) {  // psi' = psi + v : no round ran
 #pragma unroll
-                for (int q = 0; q < KP; ++q) { yr[q] = pr[q] + x0r[q]; yi[q] = pim[q] + x0i[q]; }
+                for (int q = 0; q < KP; ++q) { yr[q] = fma(eco.a1, x0r[q], eco.a0 * pr[q]); yi[q] = fma(eco.a1, x0i[q], eco.a0 * pim[q]); }
                 KR_PAIR_PHASE(0, yr[0], yi[0], sx[0][cur ^ 1], false, sx[1][cur ^ 1], false)
                 KR_PAIR_PHASE(1, yr[1], yi[1], sx[1][cur ^ 1], true, sx[0][cur ^ 1], false)
             }

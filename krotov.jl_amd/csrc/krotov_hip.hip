@@ -85,6 +85,7 @@ struct kr_handle {
     bool herm = false;    // every control operator Hermitian: update kernel variant HERM (kr_device.h)
     bool econ = false;    // every generator Hermitian (drift and control operators): economized step polynomial in the update sweep
     double *econ_d = nullptr;   // [G][NT][KR_ECON_W] rows, rewritten from the guess pulses in front of every update sweep
+    double *skw_d = nullptr;    // [G][1 + KR_LMAX_CAP] 2-norm bounds of the anti-Hermitian parts (pair mode with a generator that is not Hermitian), or nullptr
     int poll_delay = -1;  // exchange schedule of the update sweep (KrSweepArgs::poll_delay), set by calibrate_exchange
     unsigned long long *peer_xmail[8]{};
     bool peers_connected = false;
@@ -266,8 +267,17 @@ static int env_int(const char *name, int dflt) {
 // One wave per row: lane k evaluates J_k, lane j the coefficient a_j (T_k's coefficients by the three-term recurrence, lane j holding
 // t_kj and taking t_k,j-1 from its neighbour), ~10 us for the N_T rows of a sweep.
 #define KR_ECON_KMAX 31
-__global__ __launch_bounds__(64) void kr_econ_rows_kernel(const double *eps, const double *dt, const double *nrm, int G, int NT, int L, double tol,
-                                                           double margin, double *rows) {
+//
+// NEARLY Hermitian generators (round 3; `skw` != nullptr: bounds of the 2-norms of the anti-Hermitian parts (M - M^dagger) / 2 of the
+// drift and the control operators, laid out as `nrm`): a Liouvillian with weak dissipation.  The numerical range of x = H dt / theta_c
+// lies in the rectangle [-1, 1] x i [-b, b], b = beta / theta_c, beta = the bound of the anti-Hermitian part of H(eps) dt for every
+// pulse value the row is used with (the kernels use a row only while theta <= theta_c, which bounds sum |eps_l| ||H_l|| and with it
+// beta <= s_0 + max_l (s_l / ||H_l||) (margin sum |eps_g,l| ||H_l|| + (margin - 1) ||H_0||)).  On the ellipse with foci +-1 through
+// the rectangle's corner, |T_k| <= (rho^k + rho^-k) / 2, and ||p(A) - f(A)|| <= (1 + sqrt 2) max over the numerical range of |p - f|
+// (Crouzeix-Palencia), so the degree is the smallest m with (1 + sqrt 2) sum_{k>m} |c_k| (rho^k + rho^-k) / 2 <= tol.  C5's
+// Liouvillian (theta 0.09, beta 0.006, rho 1.3): degree 8 against Taylor's 9.  A row that saves nothing is not written.
+__global__ __launch_bounds__(64) void kr_econ_rows_kernel(const double *eps, const double *dt, const double *nrm, const double *skw, int G, int NT, int L,
+                                                           double tol, double margin, double *rows) {
     __shared__ double c[64];
     const int idx = blockIdx.x, lane = threadIdx.x;
     if (idx >= G * NT) return;
@@ -275,10 +285,38 @@ __global__ __launch_bounds__(64) void kr_econ_rows_kernel(const double *eps, con
     double *row = rows + (size_t)idx * KR_ECON_W;
     double th = nrm[(size_t)g * (1 + KR_LMAX_CAP)];
     for (int l = 0; l < L && l < KR_LMAX_CAP; ++l) th += fabs(eps[(size_t)l * NT + n]) * nrm[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l];
+    double beta = 0.0;
+    if (skw) {
+        const double n0 = nrm[(size_t)g * (1 + KR_LMAX_CAP)];
+        double ratio = 0.0, ctl = 0.0;
+        bool unbounded = false;
+        for (int l = 0; l < L && l < KR_LMAX_CAP; ++l) {
+            const double nl = nrm[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l], sl = skw[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l];
+            ctl += fabs(eps[(size_t)l * NT + n]) * nl;
+            if (sl > 0.0) { if (nl > 0.0) ratio = fmax(ratio, sl / nl); else unbounded = true; }
+        }
+        beta = skw[(size_t)g * (1 + KR_LMAX_CAP)] + ratio * (margin * ctl + (margin - 1.0) * n0);
+        beta *= fabs(dt[n]);
+        if (unbounded) th = 0.0;   // (cannot happen: the 2-norm bound of an operator is not below that of its anti-Hermitian part)
+    }
     th *= fabs(dt[n]) * margin;
     if (!(th > 0.0) || th > KR_THETA_MAX) {   // no row: the step takes the Taylor plan
         if (lane < KR_ECON_W) row[lane] = 0.0;
         return;
+    }
+    // weight of |c_k| in the tail: 1 on the segment; (1 + sqrt 2) (rho^k + rho^-k) / 2 on the ellipse (see above)
+    double wgt = 1.0;
+    if (beta > 0.0) {
+        const double b = beta / th;
+        const double ae = 0.5 * (sqrt(4.0 + b * b) + b);           // semi-major axis of the ellipse with foci +-1 through (1, b)
+        const double rho = ae + sqrt(fmax(ae * ae - 1.0, 0.0));
+        if (rho * th > 2.0) {   // far from Hermitian: the weighted coefficients beyond KR_ECON_KMAX would no longer be negligible -- no row
+            if (lane < KR_ECON_W) row[lane] = 0.0;
+            return;
+        }
+        double rk = 1.0;
+        for (int k = 0; k < lane && k < KR_ECON_KMAX + 1; ++k) rk *= rho;
+        wgt = 2.414213562373096 * 0.5 * (rk + 1.0 / rk);
     }
     {   // c_k = (2 - delta_k0) J_k(th): (th/2)^k / k!  x  sum_i (-th^2/4)^i / (i! (k+1)...(k+i))
         const double half = 0.5 * th, q = -half * half;
@@ -290,6 +328,12 @@ __global__ __launch_bounds__(64) void kr_econ_rows_kernel(const double *eps, con
     }
     __syncthreads();
     double tail = 0.0;
+    if (beta > 0.0) {   // (the weights differ per k: weigh first, in place of c -- the coefficients themselves are read from `cw` below)
+        __shared__ double cw[64];
+        cw[lane] = fabs(c[lane]) * wgt;
+        __syncthreads();
+        for (int k = KR_ECON_KMAX; k >= lane && k >= 0; --k) tail += cw[k];
+    } else
     for (int k = KR_ECON_KMAX; k >= lane && k >= 0; --k) tail += fabs(c[k]);   // sum_{k >= lane} |c_k|
     const unsigned long long over = __ballot(lane >= 2 && lane <= KR_ECON_KMAX && tail > tol);
     const int m = over ? (63 - __builtin_clzll(over)) : 1;   // smallest m >= 1 with sum_{k > m} |c_k| <= tol
@@ -757,7 +801,7 @@ extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_s
 
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
-                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d,
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d, h->skw_d,
                     h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected && !h->peers_in_process)
@@ -901,6 +945,30 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     }
     // Economized step polynomial (KrEcon, kr_device.h): needs a real spectrum, i.e. EVERY operator of every generator exactly
     // Hermitian; register-resident update kernels only (N <= 64).  KROTOV_HIP_ECON = 0 switches it off.
+    // Row-split PAIR mode (round 3): also for generators that are only NEARLY Hermitian (kr_econ_rows_kernel decides per step from
+    // the bounds of the anti-Hermitian parts whether an economized row exists; KROTOV_HIP_ECON_PAIR = 0 switches that off).
+    const bool econ_pair = env_int("KROTOV_HIP_ECON", 1) != 0 && env_int("KROTOV_HIP_ECON_PAIR", 1) != 0 && h->fast_ok && !h->gen_update && h->rowsplit && h->rs_pair;
+    if (econ_pair) {
+        std::vector<double> skw((size_t)G * (1 + KR_LMAX_CAP), 0.0);
+        std::vector<zc> Ms(nn);
+        bool any = false;
+        for (int g = 0; g < G; ++g)
+            for (int m = 0; m <= L && m <= KR_LMAX_CAP; ++m) {
+                if (m > 0 && !((present[g] >> (m - 1)) & 1u)) continue;
+                const zc *M = (m == 0) ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn;
+                bool herm = true;
+                for (int c = 0; c < N; ++c)
+                    for (int r = 0; r < N; ++r) {
+                        Ms[(size_t)c * N + r] = 0.5 * (M[(size_t)c * N + r] - std::conj(M[(size_t)r * N + c]));
+                        if (Ms[(size_t)c * N + r] != zc(0.0, 0.0)) herm = false;
+                    }
+                if (!herm) { skw[(size_t)g * (1 + KR_LMAX_CAP) + m] = norm2_bound(N, Ms.data()); any = true; }
+            }
+        if (any) {
+            CHK(dalloc(&h->skw_d, skw.size()));
+            CHK(hipMemcpy(h->skw_d, skw.data(), skw.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     h->econ = env_int("KROTOV_HIP_ECON", 1) != 0 && h->fast_ok && !h->gen_update && !h->rowsplit && h->NP <= 64;
     for (int g = 0; g < G && h->econ; ++g) {
         for (int m = 0; m <= L && h->econ; ++m) {
@@ -911,6 +979,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
                     if (M[(size_t)c * N + r] != std::conj(M[(size_t)r * N + c])) { h->econ = false; break; }
         }
     }
+    if (econ_pair) h->econ = true;
     if (h->econ) {
         CHK(dalloc(&h->econ_d, (size_t)G * NT * KR_ECON_W));
         CHK(hipMemset(h->econ_d, 0, (size_t)G * NT * KR_ECON_W * sizeof(double)));
@@ -1479,6 +1548,12 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     } else if (h->rowsplit) {
         rc = rowsplit_prelaunch(h, a);
         if (rc) return rc;
+        if (h->econ && h->rs_pair) {   // economized polynomial of every step (pulses known exactly: the margin covers rounding only)
+            hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(h->G * h->cfg.NT), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT,
+                               h->cfg.L, h->tol, 1.0 + 1e-9, h->econ_d);
+            HIPCHK(h, hipGetLastError());
+            a.econ = h->econ_d;
+        }
         HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 2 : 0, h->P, h->stream, &a));
     } else if (h->precomp) {
         // all N_T step propagators in parallel, then one matvec round per step.  N = 64: both on the matrix cores
@@ -1494,7 +1569,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         if (h->econ && h->NP == 64) {   // economized polynomial of every step (the pulses are known exactly: margin = rounding only;
                                         // smaller N: building the rows costs what the saved product gains -- C2 +6 us per sweep)
             const int rows = h->G * h->cfg.NT;
-            hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->G, h->cfg.NT, h->cfg.L,
+            hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT, h->cfg.L,
                                h->tol, 1.0 + 1e-9, h->econ_d);
             HIPCHK(h, hipGetLastError());
             a.econ = h->econ_d;
@@ -1554,7 +1629,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
     if (h->econ) {   // rows of the economized step polynomial from this sweep's guess pulses (device-resident pulses included)
         const int rows = h->G * h->cfg.NT;
-        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_guess_dev, h->dt_d, h->nrm_d, h->G, h->cfg.NT, h->cfg.L,
+        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_guess_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT, h->cfg.L,
                            h->tol, 1.01, h->econ_d);
         HIPCHK(h, hipGetLastError());
         a.econ = h->econ_d;

@@ -412,3 +412,36 @@ def test_window_variant_with_generators_and_missing_controls(N, K):
         eps_new, ga, psiT1 = eng.iteration(eps, chiT, S, lam)
     assert np.max(np.abs(eps_o - eps)) > 1e-6
     assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < TOL_GA and np.max(np.abs(psiT1 - psi1_o)) < TOL_STATE
+
+
+@pytest.mark.parametrize("case", ["hermitian128", "hermitian200", "weak_dissipation", "strong_dissipation"])
+def test_economized_polynomial_in_pair_mode(oracle_c, monkeypatch, case):
+    """Row-split PAIR mode evaluates the economized step polynomial too (round 3): for Hermitian generators by the rule of the
+    register-resident kernels, and for generators that are only NEARLY Hermitian -- a generator with weak dissipation -- by
+    the ellipse bound of kr_econ_rows_kernel (Crouzeix-Palencia on an ellipse around the numerical range).  With and without
+    it (KROTOV_HIP_ECON_PAIR) the three sweeps agree far inside the parity tolerances and meet the oracle at them; far from
+    Hermitian no row saves a degree, every step takes Taylor's plan and the results are bitwise those without it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_parity as tp
+    if case == "hermitian128":
+        p = wl.dense_problem(128, 40, 96, 1, 881, 0.05, 2.0)
+    elif case == "hermitian200":
+        p = wl.dense_problem(200, 36, 48, 1, 882, 0.05, 2.0)
+    else:
+        p = wl.dense_problem(160, 36, 40, 1, 883, 0.05, 2.0)
+        g = 0.002 if case == "weak_dissipation" else 0.3
+        p["H0"] = p["H0"] - 1j * g * np.diag(np.random.default_rng(6).uniform(0, 1, 160))
+    res = {}
+    for mode in ["0", "1"]:
+        monkeypatch.setenv("KROTOV_HIP_ECON_PAIR", mode)
+        res[mode], info = tp._iterate(p)
+        assert info["KT"] == 2 and info["rowsplit_R"] >= 4, info          # pair mode
+        assert info["economized_polynomial"] == int(mode), info
+    if case == "strong_dissipation":
+        assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][2], res["0"][2])
+    else:
+        assert _rel(res["1"][0], res["0"][0]) < 1e-12
+        assert not np.array_equal(res["1"][2], res["0"][2])               # (a different polynomial did run)
+        assert np.max(np.abs(res["1"][2] - res["0"][2])) < 2e-13 * max(1.0, np.max(np.abs(res["0"][2])))
+    monkeypatch.setenv("KROTOV_HIP_ECON_PAIR", "1")
+    tp._run_case(oracle_c, p, check_storage=(case == "hermitian128"))
