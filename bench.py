@@ -424,7 +424,18 @@ def main():
             eng.iteration_functional_dev(func, eps_a.data_ptr(), eps_b.data_ptr())
             eng.synchronize()
         ok, _ = attempt("trial sweep through the peer mailboxes", trial)
-        if all_ok(ok):
+
+        def pulses_agree():
+            """every rank sums the ranks' partial sums in rank order, so the updated pulses must be BITWISE equal on all ranks;
+            a stale or torn mailbox read would show here (NaN compares unequal: also a mismatch)"""
+            lo, hi = eps_b.to(red_dev).clone(), eps_b.to(red_dev).clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            same = bool(torch.equal(lo, hi)) and bool(torch.isfinite(lo).all())
+            if not same:
+                log("the ranks' updated pulses differ after the trial sweep through the peer mailboxes")
+            return same
+        if all_ok(ok) and pulses_agree():
             eps_a, eps_b, J0 = prime(eng)      # restart from the guess: the trial iteration is not part of the run
         elif args.exchange == "mailbox":
             raise SystemExit("bench.py: --exchange mailbox requested but the trial sweep through the peer mailboxes failed")
