@@ -127,7 +127,14 @@ typedef struct kr_config {
      * KR_ERR_TIMEOUT: size it to the slowest host step.  (Occupies the first of the formerly reserved words: a v2 caller
      * that zeroed `reserved` gets the default.)                                                                          */
     int32_t spin_timeout_ms;
-    int32_t reserved[7];
+    int32_t reserved0;
+    /* Schedule and diagnostics options, "NAME=integer;NAME=integer" (separators ; , or white space), or NULL.  The names are those
+     * INTEGRATION.md lists as KROTOV_HIP_<NAME> (the prefix is optional here); an option given here takes precedence over the
+     * environment variable of the same name, which stays the fallback for the lab.  kr_create fails with KR_ERR_INVALID on a name
+     * it does not know or a value that is not an integer.  The string is parsed inside kr_create and not kept.  (Occupies formerly
+     * reserved words: a caller that zeroed `reserved` passes NULL.)                                                             */
+    const char *options;
+    int32_t reserved[4];
 } kr_config;
 
 typedef struct kr_handle kr_handle;

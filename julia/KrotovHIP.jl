@@ -76,7 +76,9 @@ struct KrConfig
     pad_::Int32
     control_poly::Ptr{Float64}
     spin_timeout_ms::Int32       # bound of the in-kernel spins; 0 = default 4000 ms
-    reserved::NTuple{7,Int32}
+    reserved0::Int32
+    options::Cstring             # "NAME=integer;..." schedule / diagnostics options (INTEGRATION.md), or C_NULL
+    reserved::NTuple{4,Int32}
 end
 
 # ---- 1. the placeholder propagator ------------------------------------------------------------------------------------
@@ -120,7 +122,7 @@ dense(op) = Matrix{ComplexF64}(Array(op))
 """Build the engine from what a finished KrotovWrk holds (workspace.jl:70-125): dense drift / dH/deps_l per distinct
 generator, tlist, initial states.  `devices`: HIP ordinals of the GPUs this one handle should drive (default: the current
 device); `prop_method`: :auto, :taylor, :cheby, :newton."""
-function Engine(wrk; devices::Vector{Int} = Int[], prop_method::Symbol = :auto, prop_tol::Float64 = 0.0, spin_timeout_ms::Int = 0)
+function Engine(wrk; devices::Vector{Int} = Int[], prop_method::Symbol = :auto, prop_tol::Float64 = 0.0, spin_timeout_ms::Int = 0, options::String = "")
     trajs = wrk.trajectories
     tlist = Vector{Float64}(wrk.result.tlist)
     controls = wrk.controls
@@ -163,9 +165,9 @@ function Engine(wrk; devices::Vector{Int} = Int[], prop_method::Symbol = :auto, 
     devs = ntuple(i -> Int32(i <= length(devices) ? devices[i] : 0), 8)
     cfg = KrConfig(KR_ABI_VERSION, N, length(tlist) - 1, K, L, G, G > 1 ? pointer(tg) : C_NULL, pointer(tlist), pointer(H0),
                    pointer(Hc), pointer(present), UInt32(1), prop_tol, -1, 0, 1, 0,
-                   0, method, 0, Int32(length(devices)), devs, 0, 0, C_NULL, Int32(spin_timeout_ms), ntuple(_ -> Int32(0), 7))
+                   0, method, 0, Int32(length(devices)), devs, 0, 0, C_NULL, Int32(spin_timeout_ms), Int32(0), Cstring(isempty(options) ? C_NULL : pointer(options)), ntuple(_ -> Int32(0), 4))
     href = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve tg tlist H0 Hc present begin
+    GC.@preserve tg tlist H0 Hc present options begin
         rc = ccall((:kr_create, LIB), Cint, (Ref{KrConfig}, Ref{Ptr{Cvoid}}), cfg, href)
     end
     check(Ptr{Cvoid}(C_NULL), rc)
@@ -187,7 +189,7 @@ function engine_for(wrk::Krotov.KrotovWrk)
         get!(ENGINES, wrk) do
             opts = wrk.fw_propagators[1].kwargs          # prop_* kwargs that init_prop_trajectory passed through
             Engine(wrk; devices = Vector{Int}(get(opts, :devices, Int[])), prop_method = get(opts, :hip_prop_method, :auto),
-                   prop_tol = Float64(get(opts, :tol, 0.0)), spin_timeout_ms = Int(get(opts, :spin_timeout_ms, 0)))
+                   prop_tol = Float64(get(opts, :tol, 0.0)), spin_timeout_ms = Int(get(opts, :spin_timeout_ms, 0)), options = String(get(opts, :hip_options, "")))
         end
     end
 end

@@ -43,7 +43,7 @@ class KrConfig(C.Structure):
         ("exchange", C.c_int32), ("prop_method", C.c_int32), ("max_workgroups", C.c_int32),
         ("n_devices", C.c_int32), ("devices", C.c_int32 * 8),
         ("control_poly_degree", C.c_int32), ("pad_", C.c_int32), ("control_poly", C.c_void_p),
-        ("spin_timeout_ms", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("spin_timeout_ms", C.c_int32), ("reserved0", C.c_int32), ("options", C.c_char_p), ("reserved", C.c_int32 * 4),
     ]
 
 

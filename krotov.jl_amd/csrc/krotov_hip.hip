@@ -39,6 +39,7 @@ struct kr_handle {
     std::vector<kr_handle *> subs;
     std::vector<int> k_off;   // [P + 1] first trajectory of every shard
     kr_config cfg{};
+    std::vector<std::pair<std::string, int>> options;   // kr_config.options, parsed
     std::string err;
     std::mutex mtx;
     int device = 0;
@@ -131,6 +132,15 @@ struct kr_handle {
     // host staging
     std::vector<double> stage;
 };
+
+static int opt_int(const kr_handle *h, const char *name, int dflt) {
+    if (h)
+        for (const auto &o : h->options) if (o.first == name) return o.second;
+    char env[96];
+    snprintf(env, sizeof env, "KROTOV_HIP_%s", name);
+    const char *s = getenv(env);
+    return (s && *s) ? atoi(s) : dflt;
+}
 
 static int fail(kr_handle *h, int code, const char *fmt, ...) {
     char buf[1024];
@@ -252,10 +262,38 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
                 }
 }
 
-static int env_int(const char *name, int dflt) {
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
+// Schedule / diagnostics options (INTEGRATION.md lists them).  A caller behind a C ABI sets them in kr_config.options
+// ("NAME=value;NAME=value", names without the KROTOV_HIP_ prefix; kept in the handle); the environment variable KROTOV_HIP_<NAME>
+// is the fallback for the lab.  kr_create rejects a name that is not in this list (a typo would otherwise be silently ignored).
+static const char *const kr_option_names[] = {
+    "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
+    "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "POLL_DELAY", "PRECOMP", "ROWSPLIT",
+    "RS_LMAX1", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
+static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
+    out.clear();
+    if (!text) return true;
+    std::string t(text);
+    size_t i = 0;
+    while (i < t.size()) {
+        size_t j = t.find_first_of(";, \t\n", i);
+        if (j == std::string::npos) j = t.size();
+        std::string tok = t.substr(i, j - i);
+        i = j + 1;
+        if (tok.empty()) continue;
+        const size_t eq = tok.find('=');
+        std::string name = tok.substr(0, eq);
+        if (name.rfind("KROTOV_HIP_", 0) == 0) name = name.substr(11);
+        bool known = false;
+        for (const char *k : kr_option_names) known = known || name == k;
+        char *end = nullptr;
+        const std::string val = (eq == std::string::npos) ? std::string() : tok.substr(eq + 1);
+        const long v = val.empty() ? 0 : strtol(val.c_str(), &end, 10);
+        if (!known || val.empty() || (end && *end)) { bad = tok; return false; }
+        out.emplace_back(name, (int)v);
+    }
+    return true;
 }
+static int opt_int(const kr_handle *h, const char *name, int dflt);
 
 // ---- small device kernels for the standard functionals ---------------------
 // tau_k = <tgt_k|psi_k(T)>  (taus!, optimize.jl:381); one wave per trajectory.
@@ -513,16 +551,16 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
     int cus = prop.multiProcessorCount;
     // one persistent workgroup per CU; a handle that shares its GPU (several ranks or shards per device) gets a share:
     // kr_config.max_workgroups (a device list with repeated ordinals sets it by itself), or the environment for tests
-    int maxwg = env_int("KROTOV_HIP_MAX_WG", maxwg_cfg > 0 ? std::min(maxwg_cfg, cus) : cus);
+    int maxwg = opt_int(h, "MAX_WG", maxwg_cfg > 0 ? std::min(maxwg_cfg, cus) : cus);
     if (maxwg < 1) maxwg = 1;
-    if (NP > 64 && env_int("KROTOV_HIP_ROWSPLIT", 1) != 0) {
+    if (NP > 64 && opt_int(h, "ROWSPLIT", 1) != 0) {
         // R workgroups per trajectory, NR = NP / R rows each (8 <= NR <= 64: the H(eps) block must fit the registers)
         int R = NP / 64;
         // N = 256, one control, shared generator, more pairs than groups of 8 workgroups: the groups carry up to 4 pairs each in turn
         // (round 3: kr_rowsplit_pair_sweep<.., MULTI>; before: the streamed-generator kernels, 8 x the time per trajectory)
         int rs_sets = 1;
-        if (NP == 256 && c.L == 1 && h->G == 1 && env_int("KROTOV_HIP_RS_LMAX1", 1) != 0 && env_int("KROTOV_HIP_RS_PAIR", 1) != 0 &&
-            env_int("KROTOV_HIP_RS_SETS", 1) != 0 && maxwg >= 8 && (long long)c.K * R > maxwg) {
+        if (NP == 256 && c.L == 1 && h->G == 1 && opt_int(h, "RS_LMAX1", 1) != 0 && opt_int(h, "RS_PAIR", 1) != 0 &&
+            opt_int(h, "RS_SETS", 1) != 0 && maxwg >= 8 && (long long)c.K * R > maxwg) {
             const int groups = maxwg / 8, pairs = (c.K + 1) / 2;
             const int need = (pairs + groups - 1) / groups;
             if (need >= 2 && need <= 4) rs_sets = need;
@@ -530,11 +568,11 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
         // N <= 128 with more trajectories than half the CUs: R = 1, one workgroup per trajectory with the resident H(eps) block
         // (round 3; before: the streamed-generator kernels, (1 + L) matrices per ROUND -- 39 us per step against ~10)
         // (L <= 2: the four-control instantiation spills 2 KB per thread and loses to the streamed-generator kernels)
-        if (NP == 128 && c.L <= 2 && (long long)c.K * R > maxwg && c.K <= maxwg && env_int("KROTOV_HIP_RS_R1", 1) != 0) R = 1;
+        if (NP == 128 && c.L <= 2 && (long long)c.K * R > maxwg && c.K <= maxwg && opt_int(h, "RS_R1", 1) != 0) R = 1;
         if (((long long)c.K * R <= maxwg || rs_sets > 1) && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
             while (NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
             h->rowsplit = true;
-            if (c.L == 1 && env_int("KROTOV_HIP_RS_LMAX1", 1) != 0) h->LMAXv = 1;   // row-split kernels have an instantiation for ONE control (C5): fewer
+            if (c.L == 1 && opt_int(h, "RS_LMAX1", 1) != 0) h->LMAXv = 1;   // row-split kernels have an instantiation for ONE control (C5): fewer
                                                                                  // accumulators and chunk registers in the streaming passes
             // PAIR mode: when one trajectory per group would leave 64 rows per workgroup (the H(eps) block then fills the
             // registers, half of it in LDS, the control block is re-streamed every step and the group idles during every
@@ -542,7 +580,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             // one trajectory's all-gather behind the other's row-dot.  One control, shared generator (C5's shape); an odd K is
             // padded with one zero trajectory (it contributes nothing to any sum).  KROTOV_HIP_RS_PAIR=0 keeps the single mode.
             if (NP / R == 64 && h->LMAXv == 1 && h->G == 1 && c.K >= 2 && ((long long)((c.K + 1) / 2) * (2 * R) <= maxwg || rs_sets > 1) &&
-                env_int("KROTOV_HIP_RS_PAIR", 1) != 0) {
+                opt_int(h, "RS_PAIR", 1) != 0) {
                 h->rs_pair = true;
                 R *= 2;
             }
@@ -571,7 +609,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             return KR_OK;
         }
     }
-    int kt = env_int("KROTOV_HIP_KT", 0);
+    int kt = opt_int(h, "KT", 0);
     if (kt != 0 && kt != 1 && kt != 2 && kt != 4) return fail(h, KR_ERR_INVALID, "KROTOV_HIP_KT must be 1, 2 or 4");
     // trajectories per generator (tiles never mix generators)
     std::vector<int> count(h->G, 0);
@@ -590,7 +628,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
     // the vector kernel would carry several trajectories per team or more than two control slices (both spill there).
     // KROTOV_HIP_MFMA_SWEEP = 0 never / 1 always / unset: that rule.
     if (NP == 64) {
-        const int mf = env_int("KROTOV_HIP_MFMA_SWEEP", -1);
+        const int mf = opt_int(h, "MFMA_SWEEP", -1);
         const bool want = (mf == 1) || (mf == -1 && (kt >= 2 || h->LMAXv == 4 || tiles_for(kt) > maxwg) && kt_forced != 1);
         if (want && kt_forced != 1) {
             int ktm = (kt_forced >= 2) ? kt_forced : 2;
@@ -600,7 +638,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             // more trajectories than 4 per CU: the workgroup time-multiplexes several sets of two tiles within a step
             // (kr_mf_update<.., SETS>): K = 2048 / 4096 per GPU stay on the persistent kernel.  KROTOV_HIP_SETS fixes the count.
             if (kt == 4) {
-                const int want_sets = env_int("KROTOV_HIP_SETS", 0);
+                const int want_sets = opt_int(h, "SETS", 0);
                 if (want_sets == 1 || want_sets == 2 || want_sets == 4) h->sets = want_sets;
                 else while (h->sets < 4 && tiles_for(kt * h->sets) > maxwg) h->sets <<= 1;
             }
@@ -635,10 +673,10 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
     // ranks on the one GPU of the build box, the shape a shard of 32 trajectories has on every GPU of an 8-GPU run).
     h->wg_stride = 1;
     {
-        const int xl = env_int("KROTOV_HIP_XCD_LOCAL", 1);
+        const int xl = opt_int(h, "XCD_LOCAL", 1);
         // (an explicitly forced kernel variant -- KROTOV_HIP_HERM = 2, KROTOV_HIP_POLL_DELAY >= 0 -- keeps the ordinary launch: the
         //  placement kernel exists for the classic schedule of the general variant only)
-        const bool forced = env_int("KROTOV_HIP_HERM", 1) == 2 || env_int("KROTOV_HIP_POLL_DELAY", -2) >= 0;
+        const bool forced = opt_int(h, "HERM", 1) == 2 || opt_int(h, "POLL_DELAY", -2) >= 0;
         if (NP <= 64 && !h->mfma_sweep && h->P >= 2 && h->P <= 32 && (maxwg == cus || xl == 2) && xl != 0 && !forced) h->wg_stride = 8;
     }
     return KR_OK;
@@ -669,7 +707,7 @@ static void decide_herm(kr_handle *h, const kr_config *cfg) {
     const int N = cfg->N, L = cfg->L, G = cfg->G;
     const size_t nn = (size_t)N * N;
     const zc *Hc = (const zc *)cfg->Hc;
-    const int mode = env_int("KROTOV_HIP_HERM", 1);
+    const int mode = opt_int(h, "HERM", 1);
     // (matrix-core sweep: with one tile per workgroup the window hides phase A -- K = 512: 8.0k against ~8.9k cycles for
     //  dot + exchange --, with two tiles its five products outlast the exchange: C4 11.74 vs 11.35 us per step)
     h->herm = (mode == 2) || (mode == 1 && (h->mfma_sweep ? h->KT == 2 : h->KT == 1) && h->P >= 64 && h->NP <= 64);
@@ -678,7 +716,7 @@ static void decide_herm(kr_handle *h, const kr_config *cfg) {
     // with the next step's partial sums deposited by the step's last barrier the publish is the FIRST thing a step does, and
     // phase A hides behind the L2 round trips -- C2 3.50 -> see DESIGN.md) or the general variant with the classic schedule
     // (N = 64: five row-dots of window outlast the L2 round trips: 5.00 vs 5.16 us per step at K = 16 -- general variant there)
-    if (h->wg_stride > 1) h->herm = (mode != 0) && h->KT == 1 && h->NP <= 32 && env_int("KROTOV_HIP_XLOC_HERM", 1) != 0;
+    if (h->wg_stride > 1) h->herm = (mode != 0) && h->KT == 1 && h->NP <= 32 && opt_int(h, "XLOC_HERM", 1) != 0;
     if (h->mfma_sweep && h->LMAXv == 4 && h->KT == 4) h->herm = false;   // that instantiation spills (212 B): general variant
     if (h->rowsplit || h->NP > 64) h->herm = false;
     for (int g = 0; g < G && h->herm; ++g) {
@@ -698,7 +736,7 @@ static void decide_herm(kr_handle *h, const kr_config *cfg) {
 static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_gen) {
     const kr_config &c = h->cfg;
     const int32_t *tg = full->traj_generator;
-    const int genv = env_int("KROTOV_HIP_GENERIC", -1);
+    const int genv = opt_int(h, "GENERIC", -1);
     if (c.L > 32) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > 32 controls not supported", c.L);
     if (c.exchange < KR_EXCHANGE_AUTO || c.exchange > KR_EXCHANGE_CALLBACK) return fail(h, KR_ERR_INVALID, "kr_create: exchange = %d", c.exchange);
     if (c.prop_method < KR_PROP_AUTO || c.prop_method > KR_PROP_NEWTON) return fail(h, KR_ERR_INVALID, "kr_create: prop_method = %d", c.prop_method);
@@ -834,7 +872,7 @@ static hipError_t dalloc(T **p, size_t count) {
 // fine-grained memory: no gain (7.17-7.25); with few workgroups ordinary memory is slightly faster (C2, P = 8: 4.16
 // against 4.22).  KROTOV_HIP_MAIL_MEM = 0 (hipMalloc) / 1 (uncached) / 2 (fine-grained) overrides the choice.
 static hipError_t alloc_mailbox(kr_handle *h, unsigned long long **p, size_t words, int pollers) {
-    const int mm = env_int("KROTOV_HIP_MAIL_MEM", pollers >= 64 ? 1 : 0);
+    const int mm = opt_int(h, "MAIL_MEM", pollers >= 64 ? 1 : 0);
     (void)h;
     if (mm != 0) {
         const hipError_t e = hipExtMallocWithFlags((void **)p, std::max<size_t>(words, 1) * sizeof(unsigned long long),
@@ -879,6 +917,15 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     live = h;
     if (cfg->spin_timeout_ms > 0) h->spin_ticks = (unsigned long long)cfg->spin_timeout_ms * 100000ull;   // s_memrealtime: 100 MHz
     h->cfg = *cfg;
+    h->cfg.options = nullptr;
+    {
+        std::string bad;
+        if (!parse_options(cfg->options, h->options, bad)) {
+            live = nullptr;
+            delete h;
+            return fail(nullptr, KR_ERR_INVALID, "kr_create: kr_config.options: '%s' is not NAME=integer with a known NAME (INTEGRATION.md lists them)", bad.c_str());
+        }
+    }
     h->cfg.traj_generator = nullptr; h->cfg.tlist = nullptr; h->cfg.H0 = nullptr; h->cfg.Hc = nullptr; h->cfg.hc_present = nullptr;
     if (h->cfg.K_global <= 0) h->cfg.K_global = cfg->K;
     h->device = dev;
@@ -947,7 +994,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     // Hermitian; register-resident update kernels only (N <= 64).  KROTOV_HIP_ECON = 0 switches it off.
     // Row-split PAIR mode (round 3): also for generators that are only NEARLY Hermitian (kr_econ_rows_kernel decides per step from
     // the bounds of the anti-Hermitian parts whether an economized row exists; KROTOV_HIP_ECON_PAIR = 0 switches that off).
-    const bool econ_pair = env_int("KROTOV_HIP_ECON", 1) != 0 && env_int("KROTOV_HIP_ECON_PAIR", 1) != 0 && h->fast_ok && !h->gen_update && h->rowsplit && h->rs_pair;
+    const bool econ_pair = opt_int(h, "ECON", 1) != 0 && opt_int(h, "ECON_PAIR", 1) != 0 && h->fast_ok && !h->gen_update && h->rowsplit && h->rs_pair;
     if (econ_pair) {
         std::vector<double> skw((size_t)G * (1 + KR_LMAX_CAP), 0.0);
         std::vector<zc> Ms(nn);
@@ -969,7 +1016,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
             CHK(hipMemcpy(h->skw_d, skw.data(), skw.size() * sizeof(double), hipMemcpyHostToDevice));
         }
     }
-    h->econ = env_int("KROTOV_HIP_ECON", 1) != 0 && h->fast_ok && !h->gen_update && !h->rowsplit && h->NP <= 64;
+    h->econ = opt_int(h, "ECON", 1) != 0 && h->fast_ok && !h->gen_update && !h->rowsplit && h->NP <= 64;
     for (int g = 0; g < G && h->econ; ++g) {
         for (int m = 0; m <= L && h->econ; ++m) {
             if (m > 0 && !((present[g] >> (m - 1)) & 1u)) continue;
@@ -1080,7 +1127,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         // vector mailboxes [K][2][NP][4] + one word per workgroup (XCD ids, see kr_rowsplit_sweep); ordinary cached
         // memory: the XCD-local path of the all-gather lives on L2 hits
         h->gmail_words = (size_t)h->Kp * 2 * NP * 4 + (size_t)h->P;
-        h->xcd_group = ((h->Kp / h->KT) % 8 == 0) && env_int("KROTOV_HIP_XCD_GROUP", 1) != 0;   // (tiles % 8: pairs in pair mode)
+        h->xcd_group = ((h->Kp / h->KT) % 8 == 0) && opt_int(h, "XCD_GROUP", 1) != 0;   // (tiles % 8: pairs in pair mode)
         CHK(dalloc(&h->gmail_d, h->gmail_words));
         CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
         if (h->rs_sets > 1) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * 4 /* KR_PAIR_MAX_SETS */ * 2 * NP));
@@ -1105,8 +1152,8 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     // (NT * NP^2 * 16 B) within a budget; KROTOV_HIP_PRECOMP=0 keeps the Taylor sweeps.
     {
         const size_t ubytes = (size_t)G * NT * NP * NP * sizeof(double2);
-        h->precomp = h->fast_ok && (NP <= 64) && env_int("KROTOV_HIP_PRECOMP", 1) != 0 && ubytes <= ((size_t)8 << 30);
-        h->use_mfma = env_int("KROTOV_HIP_EXPM_MFMA", 1) != 0;
+        h->precomp = h->fast_ok && (NP <= 64) && opt_int(h, "PRECOMP", 1) != 0 && ubytes <= ((size_t)8 << 30);
+        h->use_mfma = opt_int(h, "EXPM_MFMA", 1) != 0;
         if (h->precomp) CHK(dalloc(&h->U_d, (size_t)G * NT * NP * NP));
     }
     CHK(dalloc(&h->tau_d, h->Kp));
@@ -1125,7 +1172,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
     CHK(dalloc(&h->debug_d, 8 + 8 * 1024));   // 8 phase stamps + per-workgroup arrival stamps of diagnostic builds (KR_ARRIVALS)
     CHK(hipMemset(h->debug_d, 0, (8 + 8 * 1024) * sizeof(unsigned long long)));
-    h->debug_on = env_int("KROTOV_HIP_STAMPS", 0) != 0;
+    h->debug_on = opt_int(h, "STAMPS", 0) != 0;
     CHK(dalloc(&h->status_d, KR_STATUS_WORDS));
     CHK(hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
     if (cfg->world > 1) {
@@ -1297,7 +1344,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.tol = h->tol;
     a.spin_ticks = h->spin_ticks;
     memcpy(a.thr, h->thr, sizeof a.thr);
-    a.use_mfma = h->use_mfma ? (1 | (env_int("KROTOV_HIP_EXPM_PS", 1) != 0 ? 2 : 0)) : 0;   // bit 1: Paterson-Stockmeyer form of the matrix-core propagator build
+    a.use_mfma = h->use_mfma ? (1 | (opt_int(h, "EXPM_PS", 1) != 0 ? 2 : 0)) : 0;   // bit 1: Paterson-Stockmeyer form of the matrix-core propagator build
     a.gmail = h->gmail_d;
     a.xcd_group = h->xcd_group ? 1 : 0;
     a.rs_sets = h->rs_sets;
@@ -1315,12 +1362,12 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.debug = h->debug_on ? h->debug_d : nullptr;
     a.mail = h->mail_d;
     a.poll_delay = h->poll_delay;
-    if (h->rowsplit && h->poll_delay < 0) a.poll_delay = env_int("KROTOV_HIP_RS_POLL_DELAY", 12);   // row-split update sweep: kr_exchange<.., SCHED = 1> (KR_RS_SCHED)
-    a.xpoll_delay = env_int("KROTOV_HIP_XPOLL_DELAY", 0);
+    if (h->rowsplit && h->poll_delay < 0) a.poll_delay = opt_int(h, "RS_POLL_DELAY", 12);   // row-split update sweep: kr_exchange<.., SCHED = 1> (KR_RS_SCHED)
+    a.xpoll_delay = opt_int(h, "XPOLL_DELAY", 0);
     // row-split all-gather: polling starts 9 x 128 cycles (0.48 us) after the block was handed to the publishing wave;
     // measured at C5 (forward sweep, us per step): 0 -> 32.4, 4 -> 31.5, 8 -> 30.6, 10 -> 30.4, 12 -> 31.0, 16 -> 32.8, 20 -> 34.7
-    a.gather_delay = env_int("KROTOV_HIP_GATHER_DELAY", 9);
-    a.gather_delay_local = env_int("KROTOV_HIP_GATHER_DELAY_LOCAL", 2);  // C5 forward sweep: 0 -> 26.4, 4 -> 25.8, 6 -> 25.5, 8 -> 26.1 us per step
+    a.gather_delay = opt_int(h, "GATHER_DELAY", 9);
+    a.gather_delay_local = opt_int(h, "GATHER_DELAY_LOCAL", 2);  // C5 forward sweep: 0 -> 26.4, 4 -> 25.8, 6 -> 25.5, 8 -> 26.1 us per step
     a.xmail = h->xmail_d;
     for (int r = 0; r < 8; ++r) a.peer_xmail[r] = h->peer_xmail[r];
 }
@@ -1501,7 +1548,7 @@ static int launch_update_stepped(kr_handle *h, const double *eps_guess_dev, doub
     // One rank (the sum stays on the device), L <= 32: TWO launches per time step instead of four -- the pulse update sums the
     // tiles' partials itself, the forward step adds the partial sums of the next step (kr_device_generic.h; round 3).  The
     // stepped sweep is a chain of dependent launches (a HIP graph of it replays no faster: DESIGN.md section 7).
-    if (!use_rccl && !use_cb && L <= 32 && env_int("KROTOV_HIP_GENERIC_FUSED", 1) != 0) {
+    if (!use_rccl && !use_cb && L <= 32 && opt_int(h, "GENERIC_FUSED", 1) != 0) {
         g.n = 0;       // (step 0's partial sums: the plain kernel)
         HIPCHK(h, kr_launch_generic(1, h->KTG, h->gen_tiles, h->gen_lds, h->stream, &g));
         g.fused = 1;
@@ -1562,7 +1609,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         // Measured (us per step incl. the build): K = 1024: 2.51 -> 2.22, K = 512: 1.56 -> 1.44, but K = 256 (one trajectory
         // per workgroup in the vector kernel): 1.14 -> 1.26 -- both forms are bound by streaming the 64 KB of U_n into every
         // CU each step, so the matrix cores only pay where the vector kernel is VALU-bound (several trajectories per team).
-        const int mfa = env_int("KROTOV_HIP_MFMA_APPLY", -1);
+        const int mfa = opt_int(h, "MFMA_APPLY", -1);
         const bool mf_apply = h->NP == 64 && h->use_mfma && (mfa == 1 || (mfa == -1 && h->KT >= 2)) && (h->Kp % 2 == 0) &&
                               (h->G == 1 || h->KT % 2 == 0);
         a.u_layout = mf_apply ? 1 : 0;
@@ -1577,7 +1624,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         HIPCHK(h, h->launch(h->LMAXv, std::min(h->KT, 4), 2, h->cfg.NT * h->G, h->stream, &a));
         if (mf_apply) {
             int kt_a = (h->KT % 2 == 0) ? std::min(h->KT, 4) : 2;
-            const int want_a = env_int("KROTOV_HIP_MFMA_APPLY_KT", 0);   // (tuning knob: 2 or 4 trajectories per workgroup)
+            const int want_a = opt_int(h, "MFMA_APPLY_KT", 0);   // (tuning knob: 2 or 4 trajectories per workgroup)
             if ((want_a == 2 || want_a == 4) && h->Kp % want_a == 0 && (h->G == 1 || h->KT % want_a == 0 || want_a % h->KT == 0) && (h->G == 1 || want_a <= h->KT)) kt_a = want_a;
             a.gen_div = std::max(1, h->KT * h->sets / kt_a);
             HIPCHK(h, kr_launch_mf64(2, kt_a / 2, 3, h->Kp / kt_a, h->stream, &a));
@@ -1587,7 +1634,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         // generator, wider tiles (more trajectories per workgroup, fewer workgroups) cut that traffic.
         int kt_apply = std::min(h->KT, 4);   // (KT = 8 exists only for the matrix-core update sweep)
         if (h->G == 1) {
-            const int want = env_int("KROTOV_HIP_APPLY_KT", 0);
+            const int want = opt_int(h, "APPLY_KT", 0);
             for (int cand : {4, 2}) {
                 if (cand <= kt_apply) break;
                 const bool pick = (cand == want);  // measured at C3: KT 1 -> 1.24 ms, 2 -> 1.44 ms, 4 -> 2.03 ms per sweep: default = the handle's KT
@@ -1665,17 +1712,17 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
 // the schedule, only the timing does).  KROTOV_HIP_POLL_DELAY fixes the value (-1 = classic), KROTOV_HIP_CALIBRATE=0
 // skips the measurement.
 static int calibrate_exchange(kr_handle *h) {
-    const int fixed = env_int("KROTOV_HIP_POLL_DELAY", -2);
+    const int fixed = opt_int(h, "POLL_DELAY", -2);
     if (fixed != -2) { h->poll_delay = fixed; return KR_OK; }
     // (N > 64: a step holds ~9 memory round trips of which the exchange is one: not worth 0.2 s of calibration)
-    if (h->gen_update || h->P < 64 || h->NP > 64 || !env_int("KROTOV_HIP_CALIBRATE", 1)) return KR_OK;
+    if (h->gen_update || h->P < 64 || h->NP > 64 || !opt_int(h, "CALIBRATE", 1)) return KR_OK;
     // One measurement per process and launch shape: later handles of the same shape reuse it (the schedule then no longer
     // depends on the timing noise of every single kr_create, and the ~30 calibration sweeps are paid once).
     // KROTOV_HIP_CALIBRATE_CACHE=0 measures every time.
     static std::mutex cal_mtx;
     static std::vector<std::pair<std::vector<int>, int>> cal_cache;
     const std::vector<int> key = {h->device, h->NP, h->LMAXv, h->KT, h->P, h->herm ? 1 : 0, h->mfma_sweep ? 1 : 0, h->cfg.L, h->cfg.N, h->sets, h->wg_stride};
-    const bool use_cache = env_int("KROTOV_HIP_CALIBRATE_CACHE", 1) != 0;
+    const bool use_cache = opt_int(h, "CALIBRATE_CACHE", 1) != 0;
     if (use_cache) {
         std::lock_guard<std::mutex> g(cal_mtx);
         for (auto &c : cal_cache) if (c.first == key) { h->poll_delay = c.second; return KR_OK; }

@@ -16,7 +16,7 @@ from . import _capi as capi
 class HipEngine:
     def __init__(self, H0, Hc, tlist, K, *, hc_present=None, traj_generator=None, store_fw=True, prop_tol=0.0,
                  device=-1, rank=0, world=1, K_global=0, exchange=0, prop_method=0, max_workgroups=0, devices=None,
-                 control_poly=None, spin_timeout_ms=0):
+                 control_poly=None, spin_timeout_ms=0, options=None):
         """H0 (N,N) and Hc (L,N,N) for a generator shared by all trajectories, or H0 (G,N,N), Hc (G,L,N,N)
         with traj_generator[k] in 0..G-1 for per-trajectory generators (control_derivs[k][l],
         /root/reference/src/workspace.jl:74)."""
@@ -67,6 +67,11 @@ class HipEngine:
             for i, d in enumerate(devices):
                 cfg.devices[i] = int(d)
         cfg.spin_timeout_ms = int(spin_timeout_ms)   # bound of the in-kernel spins; 0 = default 4000 ms
+        # kr_config.options: schedule / diagnostics options ("NAME=integer;..." or a dict); parsed inside kr_create
+        if isinstance(options, dict):
+            options = ";".join("%s=%d" % (k, int(v)) for k, v in options.items())
+        self._options = options.encode() if options else None
+        cfg.options = self._options
         self._cb = None
         self._poly = None
         if control_poly is not None:   # f_l(x) = sum_p control_poly[l][p] x^p  (non-linear controls, static part)

@@ -41,8 +41,9 @@ def test_abi_version(lib):
 
 def test_config_struct_layout():
     # mirrors `struct kr_config` (include/krotov_hip.h, ABI v2): 6 ints, 5 pointers, flags (+ pad), double, 4 ints,
-    # 4 + 8 ints of v2, control_poly (2 ints + pointer), 8 reserved
-    assert C.sizeof(capi.KrConfig) == 24 + 40 + 4 + 4 + 8 + 16 + 16 + 32 + 16 + 32
+    # 4 + 8 ints of v2, control_poly (2 ints + pointer), spin bound + pad, options pointer, 4 reserved
+    assert C.sizeof(capi.KrConfig) == 24 + 40 + 4 + 4 + 8 + 16 + 16 + 32 + 16 + 8 + 8 + 16
+    assert capi.KrConfig.options.offset == 168 and capi.KrConfig.spin_timeout_ms.offset == 160
 
 
 def _gpu_present():

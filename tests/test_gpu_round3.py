@@ -445,3 +445,26 @@ def test_economized_polynomial_in_pair_mode(oracle_c, monkeypatch, case):
         assert np.max(np.abs(res["1"][2] - res["0"][2])) < 2e-13 * max(1.0, np.max(np.abs(res["0"][2])))
     monkeypatch.setenv("KROTOV_HIP_ECON_PAIR", "1")
     tp._run_case(oracle_c, p, check_storage=(case == "hermitian128"))
+
+
+def test_options_travel_in_kr_config(monkeypatch):
+    """Schedule options are part of kr_config (`options`, "NAME=integer;..."): what a caller behind the C ABI uses instead of the
+    KROTOV_HIP_* environment variables, which stay the fallback.  An option in kr_config wins over the environment; a name the
+    library does not know, or a value that is not an integer, fails kr_create with a message instead of being ignored."""
+    p = wl.dense_problem(128, 6, 96, 1, 884, 0.05, 2.0)
+    K = p["psi0"].shape[0]
+
+    def plan(**kw):
+        with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, **kw) as eng:
+            return eng.info()
+    monkeypatch.delenv("KROTOV_HIP_RS_PAIR", raising=False)
+    assert plan()["KT"] == 2                                             # pair mode by default at this shape
+    assert plan(options={"RS_PAIR": 0})["KT"] == 1
+    assert plan(options="KROTOV_HIP_RS_PAIR=0; ECON=0")["KT"] == 1       # prefix optional, several separators
+    monkeypatch.setenv("KROTOV_HIP_RS_PAIR", "0")
+    assert plan()["KT"] == 1                                             # the environment is the fallback ...
+    assert plan(options="RS_PAIR=1")["KT"] == 2                          # ... and kr_config wins over it
+    for bad in ["RS_PEAR=0", "RS_PAIR=yes", "RS_PAIR"]:
+        with pytest.raises(Exception) as ei:
+            plan(options=bad)
+        assert "options" in str(ei.value) and bad in str(ei.value)
