@@ -16,6 +16,7 @@ restated here: they are the C ABI calls kr_forward / kr_iteration of libkrotov_h
 No CPU implementation of them exists in this package.
 """
 import datetime as _dt
+import os
 import sys
 import time
 
@@ -449,6 +450,19 @@ def optimize_krotov(problem):
     if info is not None and len(info) > 0:
         wrk.result.records.append(tuple(info))
     i = wrk.result.iter
+    # atexit_filename (optimize.jl:195-206; undocumented in the reference on purpose: the hook of @optimize_or_load): the result as
+    # it stands is written there if the interpreter exits unexpectedly while the loop runs; the hook is removed afterwards (:229-231)
+    atexit_filename = kw.get("atexit_filename", None)
+    atexit_hook = None
+    if atexit_filename is not None:
+        import atexit
+        import pickle
+
+        def atexit_hook(result=wrk.result, filename=atexit_filename):
+            with open(filename, "wb") as f:
+                pickle.dump(result, f)
+        atexit.register(atexit_hook)
+        print("Info: Set callback to store result in %s on unexpected exit." % os.path.relpath(atexit_filename), file=sys.stderr)
     try:
         while not wrk.result.converged:
             i += 1
@@ -468,6 +482,9 @@ def optimize_krotov(problem):
     res.end_local_time = _dt.datetime.now()
     for l in range(len(eps_i)):
         res.optimized_controls[l] = discretize(eps_i[l], res.tlist)
+    if atexit_hook is not None:
+        import atexit
+        atexit.unregister(atexit_hook)
     if hasattr(wrk.engine, "close") and not kw.get("keep_engine", False):
         wrk.engine.close()
     return res

@@ -203,3 +203,48 @@ def test_prop_callbacks_are_replayed():
     problem = tls_problem(iter_stop=1, J_T=kr.J_T_sm, fw_prop_callback=fw_cb, bw_prop_callback=bw_cb, keep_engine=True)
     kr.optimize(problem, print_iters=False)
     assert seen["fw"] == 2 * 500 and seen["bw"] == 500   # initial sweep + iteration 1; one backward sweep
+
+
+def test_atexit_filename_saves_the_result_on_unexpected_exit(tmp_path):
+    """optimize.jl:195-206, 229-231: with `atexit_filename` the result as it stands is stored if the interpreter exits while the
+    optimization runs (here: a callback that ends the process in iteration 2), and the hook is gone once optimize returns."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "result.pkl"
+    script = textwrap.dedent("""
+        import sys
+        sys.path[:0] = [%r, %r, %r]
+        import test_host_logic as t
+        import krotov_jl_amd as kr
+        def cb(wrk, it, *a):
+            if it == 2:
+                sys.exit(3)          # an exit the optimization loop does not see to its end
+        try:
+            kr.optimize(t.tls_problem(iter_stop=5, J_T=kr.J_T_sm, atexit_filename=%r), callback=cb, print_iters=False,
+                        rethrow_exceptions=True)
+        except SystemExit:
+            raise
+        """) % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), str(out))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3, r.stderr[-2000:]
+    assert "Set callback to store result" in r.stderr
+    with open(out, "rb") as f:
+        res = pickle.load(f)
+    assert res.iter == 2 and res.J_T < res.J_T_prev and len(res.optimized_controls) == 1
+    # a run that ends normally removes the hook: nothing is written at interpreter exit
+    out2 = tmp_path / "unused.pkl"
+    script2 = textwrap.dedent("""
+        import sys
+        sys.path[:0] = [%r, %r, %r]
+        import test_host_logic as t
+        import krotov_jl_amd as kr
+        res = kr.optimize(t.tls_problem(iter_stop=1, J_T=kr.J_T_sm, atexit_filename=%r), print_iters=False)
+        assert res.iter == 1
+        """) % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), str(out2))
+    r = subprocess.run([sys.executable, "-c", script2], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert not out2.exists()
