@@ -305,6 +305,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, a.wg_gen ? a.wg_gen[tile] : 0);
     const int xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
+    const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
     const size_t slab = (size_t)a.Kp * N;
     const size_t kbase = (size_t)tile * N;
 
@@ -372,6 +373,8 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
         double e[LMAX], eg[LMAX], de[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) { eg[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0; e[l] = eg[l]; de[l] = 0.0; }
+        // row of the step's economized polynomial (lane j: entry j; kr_device.h: KrEcon), consumed behind the exchange; 0 = Taylor's plan
+        const double ec = econ_rows ? econ_rows[(size_t)n * KR_ECON_W] : 0.0;
         double orr[1 + LMAX], oi[1 + LMAX];
         const bool refresh = (step % KR_RS_REFRESH) == 0;   // rebuild H(eps) from H0; otherwise add (eps - ecur) H_l
         double dinc[LMAX];
@@ -418,6 +421,11 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
         theta *= fabs(sdt);
         int s, m;
         kr_plan_fast(a, my_thr, theta, s, m);
+        int se = s, me = m;
+        KrEcon eco = kr_econ_select(ec, theta, se, me);
+        if (eco.on && (s > 1 || me < m)) { s = se; m = me; }          // (a row whose degree saves nothing is not used)
+        else { eco.on = false; eco.a0 = 1.0; eco.a1 = 1.0; }
+        const double my_g = eco.on ? ec : my_rinv;   // Horner ratios of this step, lane j holds g_j
         const double fs = (s == 1) ? sdt : sdt / (double)s;
 
         for (int sub = 0; sub < s; ++sub) {
@@ -439,13 +447,15 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
             }
             double yr = x0r, yi = x0i;
             for (int j = m; j >= jlast; --j) {
-                const double f = fs * kr_rinv_lane(my_rinv, j);
+                const bool last = (j == jlast);
+                // (known-pulse form, last round: a_0 psi + a_1 z y_1 -- entry 1 of the row is a_1 itself, not a ratio; Taylor: 1, 1)
+                const bool scale0 = !have_v && last;
+                const double f = scale0 ? fs * eco.a1 : fs * kr_rinv_lane(my_g, j);
                 double sr, si;
                 kr_rs_row_dot<JS, JSR, JQ, (JS >= 8 ? 8 : JS), G::THREADS>(Er, Ei, sHl, src + xoff, sr, si);
-                yr = fma(f, si, x0r);
-                yi = fma(-f, sr, x0i);
-                const bool last = (j == jlast);
-                if (last && have_v) { yr += pr; yi += pim; }   // psi' = psi + y_1
+                yr = fma(f, si, scale0 ? eco.a0 * x0r : x0r);
+                yi = fma(-f, sr, scale0 ? eco.a0 * x0i : x0i);
+                if (last && have_v) { yr = fma(eco.a1, yr, eco.a0 * pr); yi = fma(eco.a1, yi, eco.a0 * pim); }   // psi' = a_0 psi + a_1 y_1  (Taylor: 1, 1)
                 double2 *dst = last ? sx[cur ^ 1] : sy[w];
                 KR_STAMP(tD)
                 if (!kr_group_gather<NP, NR, JS>(a, box, rb, owner, il, yr, yi, dst, sflag)) return;
@@ -455,7 +465,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
                 w ^= 1;
             }
             if (have_v && m == 1) {  // psi' = psi + v : no round ran
-                yr = pr + x0r; yi = pim + x0i;
+                yr = fma(eco.a1, x0r, eco.a0 * pr); yi = fma(eco.a1, x0i, eco.a0 * pim);
                 if (!kr_group_gather<NP, NR, JS>(a, box, rb, owner, il, yr, yi, sx[cur ^ 1], sflag)) return;
             }
             pr = yr; pim = yi;

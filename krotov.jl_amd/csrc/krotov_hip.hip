@@ -994,7 +994,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     // Hermitian; register-resident update kernels only (N <= 64).  KROTOV_HIP_ECON = 0 switches it off.
     // Row-split PAIR mode (round 3): also for generators that are only NEARLY Hermitian (kr_econ_rows_kernel decides per step from
     // the bounds of the anti-Hermitian parts whether an economized row exists; KROTOV_HIP_ECON_PAIR = 0 switches that off).
-    const bool econ_pair = opt_int(h, "ECON", 1) != 0 && opt_int(h, "ECON_PAIR", 1) != 0 && h->fast_ok && !h->gen_update && h->rowsplit && h->rs_pair;
+    const bool econ_pair = opt_int(h, "ECON", 1) != 0 && opt_int(h, "ECON_PAIR", 1) != 0 && h->fast_ok && !h->gen_update && h->rowsplit;
     if (econ_pair) {
         std::vector<double> skw((size_t)G * (1 + KR_LMAX_CAP), 0.0);
         std::vector<zc> Ms(nn);
@@ -1595,7 +1595,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     } else if (h->rowsplit) {
         rc = rowsplit_prelaunch(h, a);
         if (rc) return rc;
-        if (h->econ && h->rs_pair) {   // economized polynomial of every step (pulses known exactly: the margin covers rounding only)
+        if (h->econ) {   // economized polynomial of every step (pulses known exactly: the margin covers rounding only)
             hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(h->G * h->cfg.NT), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT,
                                h->cfg.L, h->tol, 1.0 + 1e-9, h->econ_d);
             HIPCHK(h, hipGetLastError());

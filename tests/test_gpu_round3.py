@@ -414,28 +414,41 @@ def test_window_variant_with_generators_and_missing_controls(N, K):
     assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < TOL_GA and np.max(np.abs(psiT1 - psi1_o)) < TOL_STATE
 
 
-@pytest.mark.parametrize("case", ["hermitian128", "hermitian200", "weak_dissipation", "strong_dissipation"])
-def test_economized_polynomial_in_pair_mode(oracle_c, monkeypatch, case):
-    """Row-split PAIR mode evaluates the economized step polynomial too (round 3): for Hermitian generators by the rule of the
-    register-resident kernels, and for generators that are only NEARLY Hermitian -- a generator with weak dissipation -- by
-    the ellipse bound of kr_econ_rows_kernel (Crouzeix-Palencia on an ellipse around the numerical range).  With and without
-    it (KROTOV_HIP_ECON_PAIR) the three sweeps agree far inside the parity tolerances and meet the oracle at them; far from
-    Hermitian no row saves a degree, every step takes Taylor's plan and the results are bitwise those without it."""
+@pytest.mark.parametrize("case", ["hermitian128", "hermitian200", "weak_dissipation", "strong_dissipation",
+                                  "single_r1", "single_two_controls", "single_generators"])
+def test_economized_polynomial_in_rowsplit_kernels(oracle_c, monkeypatch, case):
+    """The row-split kernels (64 < N <= 256; pair mode and single mode, R = 1 included) evaluate the economized step polynomial too
+    (round 3), in all three sweeps: for Hermitian generators by the rule of the register-resident kernels, and for generators that
+    are only NEARLY Hermitian -- weak dissipation -- by the ellipse bound of kr_econ_rows_kernel (Crouzeix-Palencia on an ellipse
+    around the numerical range).  With and without it (KROTOV_HIP_ECON_PAIR) the sweeps agree far inside the parity tolerances and
+    meet the oracle at them; far from Hermitian no row saves a degree, every step takes Taylor's plan and the results are
+    bitwise those without it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_gpu_parity as tp
+    pair = True
     if case == "hermitian128":
         p = wl.dense_problem(128, 40, 96, 1, 881, 0.05, 2.0)
     elif case == "hermitian200":
         p = wl.dense_problem(200, 36, 48, 1, 882, 0.05, 2.0)
+    elif case == "single_r1":              # one workgroup per trajectory, resident generator
+        p, pair = wl.dense_problem(128, 36, 256, 1, 885, 0.05, 2.0), False
+    elif case == "single_two_controls":    # R = 8 workgroups per trajectory, two controls
+        p, pair = wl.dense_problem(200, 36, 24, 2, 886, 0.05, 2.0), False
+    elif case == "single_generators":      # per-trajectory generators, one of them not Hermitian: its steps take Taylor's plan
+        p, pair = wl.dense_problem(100, 34, 12, 2, 887, 0.05, 2.0), False
+        H0 = np.stack([p["H0"], p["H0"] * 0.9 - 0.2j * np.diag(np.random.default_rng(8).uniform(0, 1, 100))])
+        Hc = np.stack([p["Hc"], p["Hc"] * 1.1])
+        p["H0"], p["Hc"], p["traj_generator"] = H0, Hc, np.arange(12) % 2
     else:
         p = wl.dense_problem(160, 36, 40, 1, 883, 0.05, 2.0)
         g = 0.002 if case == "weak_dissipation" else 0.3
         p["H0"] = p["H0"] - 1j * g * np.diag(np.random.default_rng(6).uniform(0, 1, 160))
+    kw = {"traj_generator": p["traj_generator"]} if "traj_generator" in p else {}
     res = {}
     for mode in ["0", "1"]:
         monkeypatch.setenv("KROTOV_HIP_ECON_PAIR", mode)
-        res[mode], info = tp._iterate(p)
-        assert info["KT"] == 2 and info["rowsplit_R"] >= 4, info          # pair mode
+        res[mode], info = tp._iterate(p, **kw)
+        assert info["rowsplit_R"] >= 1 and info["KT"] == (2 if pair else 1), info
         assert info["economized_polynomial"] == int(mode), info
     if case == "strong_dissipation":
         assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][2], res["0"][2])
@@ -444,7 +457,14 @@ def test_economized_polynomial_in_pair_mode(oracle_c, monkeypatch, case):
         assert not np.array_equal(res["1"][2], res["0"][2])               # (a different polynomial did run)
         assert np.max(np.abs(res["1"][2] - res["0"][2])) < 2e-13 * max(1.0, np.max(np.abs(res["0"][2])))
     monkeypatch.setenv("KROTOV_HIP_ECON_PAIR", "1")
-    tp._run_case(oracle_c, p, check_storage=(case == "hermitian128"))
+    if case != "single_generators":
+        tp._run_case(oracle_c, p, check_storage=(case == "hermitian128"))
+    else:   # per-trajectory generators: the serial restatement on the oracle's exact step propagator
+        import krotov_oracle as o
+        tg = p["traj_generator"]
+        _, _, eps_o, ga_o, psi1_o = _serial_iteration(o, p["H0"], p["Hc"], np.ones((2, 2), np.uint8), tg, p["tlist"], p["eps"], p["S"], p["lam"],
+                                                      p["psi0"], p["tgt"])
+        assert _rel(res["1"][0], eps_o) < TOL_PULSE and np.max(np.abs(res["1"][2] - psi1_o)) < 1e-9
 
 
 def test_options_travel_in_kr_config(monkeypatch):
