@@ -107,6 +107,8 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
+    // economized step polynomial (kr_device.h: KrEcon; Hermitian or nearly Hermitian generators): lane j holds entry j of the step's row
+    const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
 
     double pr[KT], pim[KT];
     size_t kbase[KT];
@@ -134,11 +136,19 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
         theta *= fabs(sdt);
         int s, m;
         kr_plan_fast(a, my_thr, theta, s, m);
+        const double ec = econ_rows ? econ_rows[(size_t)n * KR_ECON_W] : 0.0;
+        int se = s, me = m;
+        KrEcon eco = kr_econ_select(ec, theta, se, me);
+        if (eco.on && (s > 1 || me < m)) { s = se; m = me; }          // (a row whose degree saves nothing is not used)
+        else { eco.on = false; eco.a0 = 1.0; eco.a1 = 1.0; }
+        const double my_g = eco.on ? ec : my_rinv;   // Horner ratios of this step, lane j holds g_j
         const double fs = (s == 1) ? sdt : sdt / (double)s;
         for (int sub = 0; sub < s; ++sub) {
             int w = 0;
             for (int j = m; j >= 1; --j) {
-                const double f = fs * kr_rinv_lane(my_rinv, j);
+                // (last round: a_0 psi + a_1 z y_1 -- entry 1 of the row is a_1 itself, not a ratio; Taylor: 1, 1)
+                const double f = (j == 1) ? fs * eco.a1 : fs * kr_rinv_lane(my_g, j);
+                const double c0 = (j == 1) ? eco.a0 : 1.0;
                 const double2 *xp[KT];
 #pragma unroll
                 for (int q = 0; q < KT; ++q) xp[q] = (j == m) ? &sx[cur][q][xoff] : &sy[w ^ 1][q][xoff];
@@ -146,8 +156,8 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_kn
                 kr_stream_rows<JS, JQ, RT, LMAX, KT, 1>(hrsrc, tt, L, e, xp, sr, si);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) {
-                    const double yr = fma(f, si[q][0], pr[q]);
-                    const double yi = fma(-f, sr[q][0], pim[q]);
+                    const double yr = fma(f, si[q][0], c0 * pr[q]);
+                    const double yi = fma(-f, sr[q][0], c0 * pim[q]);
                     if (j > 1) {
                         if (writer) sy[w][q][pi_] = make_double2(yr, yi);
                     } else {
@@ -191,6 +201,8 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
     const int N = a.N, NT = a.NT, L = a.L;
     const size_t slab = (size_t)a.Kp * N;
+    // economized step polynomial (kr_device.h: KrEcon; Hermitian or nearly Hermitian generators): lane j holds entry j of the step's row
+    const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
 
     double pr[KT], pim[KT], cr[KT], ci[KT];
     size_t kbase[KT];
@@ -210,6 +222,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
     int cur = 0;
     for (int n = 0; n < NT; ++n) {
         const double dt = a.dt[n];
+        const double ec = econ_rows ? econ_rows[(size_t)n * KR_ECON_W] : 0.0;
         double eg[LMAX], al[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
@@ -259,6 +272,11 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
         theta *= fabs(dt);
         int s, m;
         kr_plan_fast(a, my_thr, theta, s, m);
+        int se = s, me = m;
+        KrEcon eco = kr_econ_select(ec, theta, se, me);
+        if (eco.on && (s > 1 || me < m)) { s = se; m = me; }          // (a row whose degree saves nothing is not used)
+        else { eco.on = false; eco.a0 = 1.0; eco.a1 = 1.0; }
+        const double my_g = eco.on ? ec : my_rinv;   // Horner ratios of this step, lane j holds g_j
         const double fs = (s == 1) ? dt : dt / (double)s;
         {
             double vr[KT], vi[KT], yr[KT], yi[KT];
@@ -274,7 +292,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
             if (m > 1) __syncthreads();
             int w = 1;
             for (int j = m; j >= 2; --j) {
-                const double f = fs * kr_rinv_lane(my_rinv, j);
+                const double f = fs * kr_rinv_lane(my_g, j);
 #pragma unroll
                 for (int q = 0; q < KT; ++q) xp[q] = &sy[w ^ 1][q][xoff];
                 double sr[KT][1], si[KT][1];
@@ -290,7 +308,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
             }
 #pragma unroll
             for (int q = 0; q < KT; ++q) {
-                pr[q] += yr[q]; pim[q] += yi[q];
+                pr[q] = fma(eco.a1, yr[q], eco.a0 * pr[q]); pim[q] = fma(eco.a1, yi[q], eco.a0 * pim[q]);   // psi' = a_0 psi + a_1 y_1  (Taylor: 1, 1)
                 if (writer) sx[cur ^ 1][q][pi_] = make_double2(pr[q], pim[q]);
             }
             __syncthreads();

@@ -994,7 +994,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     // Hermitian; register-resident update kernels only (N <= 64).  KROTOV_HIP_ECON = 0 switches it off.
     // Row-split PAIR mode (round 3): also for generators that are only NEARLY Hermitian (kr_econ_rows_kernel decides per step from
     // the bounds of the anti-Hermitian parts whether an economized row exists; KROTOV_HIP_ECON_PAIR = 0 switches that off).
-    const bool econ_pair = opt_int(h, "ECON", 1) != 0 && opt_int(h, "ECON_PAIR", 1) != 0 && h->fast_ok && !h->gen_update && h->rowsplit;
+    const bool econ_pair = opt_int(h, "ECON", 1) != 0 && opt_int(h, "ECON_PAIR", 1) != 0 && h->fast_ok && !h->gen_update && (h->rowsplit || h->NP > 64);   // row-split and streamed-generator kernels
     if (econ_pair) {
         std::vector<double> skw((size_t)G * (1 + KR_LMAX_CAP), 0.0);
         std::vector<zc> Ms(nn);
@@ -1647,6 +1647,12 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     } else {
         const int kt_known = std::min(h->KT, 4);   // (KT = 8 exists only for the matrix-core update sweep)
         a.gen_div = h->KT * h->sets / kt_known;
+        if (h->econ && h->NP > 64) {   // streamed-generator kernels: economized polynomial of every step (margin: rounding only)
+            hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(h->G * h->cfg.NT), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT,
+                               h->cfg.L, h->tol, 1.0 + 1e-9, h->econ_d);
+            HIPCHK(h, hipGetLastError());
+            a.econ = h->econ_d;
+        }
         HIPCHK(h, h->launch(h->LMAXv, kt_known, 0, h->Kp / (h->SG * kt_known), h->stream, &a));
     }
     return ev_mark(h, which_ev, true);

@@ -415,9 +415,9 @@ def test_window_variant_with_generators_and_missing_controls(N, K):
 
 
 @pytest.mark.parametrize("case", ["hermitian128", "hermitian200", "weak_dissipation", "strong_dissipation",
-                                  "single_r1", "single_two_controls", "single_generators"])
+                                  "single_r1", "single_two_controls", "single_generators", "streamed"])
 def test_economized_polynomial_in_rowsplit_kernels(oracle_c, monkeypatch, case):
-    """The row-split kernels (64 < N <= 256; pair mode and single mode, R = 1 included) evaluate the economized step polynomial too
+    """The row-split and streamed-generator kernels (64 < N <= 256) evaluate the economized step polynomial too
     (round 3), in all three sweeps: for Hermitian generators by the rule of the register-resident kernels, and for generators that
     are only NEARLY Hermitian -- weak dissipation -- by the ellipse bound of kr_econ_rows_kernel (Crouzeix-Palencia on an ellipse
     around the numerical range).  With and without it (KROTOV_HIP_ECON_PAIR) the sweeps agree far inside the parity tolerances and
@@ -432,6 +432,8 @@ def test_economized_polynomial_in_rowsplit_kernels(oracle_c, monkeypatch, case):
         p = wl.dense_problem(200, 36, 48, 1, 882, 0.05, 2.0)
     elif case == "single_r1":              # one workgroup per trajectory, resident generator
         p, pair = wl.dense_problem(128, 36, 256, 1, 885, 0.05, 2.0), False
+    elif case == "streamed":               # more trajectories than the row-split plans take: streamed-generator kernels
+        p, pair = wl.dense_problem(200, 30, 70, 2, 888, 0.05, 2.0), False
     elif case == "single_two_controls":    # R = 8 workgroups per trajectory, two controls
         p, pair = wl.dense_problem(200, 36, 24, 2, 886, 0.05, 2.0), False
     elif case == "single_generators":      # per-trajectory generators, one of them not Hermitian: its steps take Taylor's plan
@@ -448,7 +450,10 @@ def test_economized_polynomial_in_rowsplit_kernels(oracle_c, monkeypatch, case):
     for mode in ["0", "1"]:
         monkeypatch.setenv("KROTOV_HIP_ECON_PAIR", mode)
         res[mode], info = tp._iterate(p, **kw)
-        assert info["rowsplit_R"] >= 1 and info["KT"] == (2 if pair else 1), info
+        if case == "streamed":
+            assert info["rowsplit_R"] == 0 and info["NP"] == 256 and info["generic_update"] == 0, info
+        else:
+            assert info["rowsplit_R"] >= 1 and info["KT"] == (2 if pair else 1), info
         assert info["economized_polynomial"] == int(mode), info
     if case == "strong_dissipation":
         assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][2], res["0"][2])
