@@ -445,6 +445,9 @@ def test_economized_polynomial_in_rowsplit_kernels(oracle_c, monkeypatch, case):
         p = wl.dense_problem(160, 36, 40, 1, 883, 0.05, 2.0)
         g = 0.002 if case == "weak_dissipation" else 0.3
         p["H0"] = p["H0"] - 1j * g * np.diag(np.random.default_rng(6).uniform(0, 1, 160))
+    if case in ("hermitian200", "single_two_controls", "streamed"):   # a non-uniform time grid: the rows follow dt_n
+        dts = np.diff(p["tlist"]) * np.random.default_rng(9).uniform(0.6, 1.4, len(p["tlist"]) - 1)
+        p["tlist"] = np.concatenate([[0.0], np.cumsum(dts)])
     kw = {"traj_generator": p["traj_generator"]} if "traj_generator" in p else {}
     res = {}
     for mode in ["0", "1"]:
