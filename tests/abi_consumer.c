@@ -80,6 +80,19 @@ int main(int argc, char **argv) {
           "L = 0 must give the reference's message (workspace.jl:72), got: %s", kr_last_error(NULL));
     cfg.L = L;
     cfg.flags = KR_STORE_FW;
+    /* schedule options travel in the config (the environment is only the fallback): an unknown name is refused with a message,
+     * a known one is accepted -- here the default value of one, so that the golden results below are those of the default plan */
+    cfg.options = "NO_SUCH_OPTION=1";
+    {
+        int rco = kr_create(&cfg, &h);
+        if (rco == KR_ERR_NO_DEVICE) {
+            printf("abi_consumer: no HIP device (%s) -- the library refuses to run without one, as documented\n", kr_last_error(NULL));
+            return 3;
+        }
+        CHECK(rco == KR_ERR_INVALID && h == NULL && strstr(kr_last_error(NULL), "NO_SUCH_OPTION") != NULL,
+              "an unknown option must be refused by name, got %d: %s", rco, kr_last_error(NULL));
+    }
+    cfg.options = "ECON=1;PRECOMP=1";
 
     /* ---- the sequence that replaces krotov_initial_fw_prop! + krotov_iteration ---- */
     int rc = kr_create(&cfg, &h);
