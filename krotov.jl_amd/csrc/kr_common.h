@@ -180,6 +180,8 @@ static inline hipError_t kr_launch_mf64(int lmax, int tiles, int kind, int grid,
 // row-split kernels (kr_device_rowsplit.h): second argument = rows per workgroup
 hipError_t kr_launch_rs128(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_rs256(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+hipError_t kr_launch_rs512(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
+hipError_t kr_launch_rs1024(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 
 // generic (multi-pass) kernels (kr_device_generic.h)
 struct KrGenArgs {
@@ -187,6 +189,7 @@ struct KrGenArgs {
     size_t gen_stride;         // elements between two generators
     double2 *Heps;             // [G][N * N] scratch: H(eps) of the current step (update sweep)
     const int *tile_gen;       // [tiles] generator of each tile (nullptr: all 0)
+    const double *econ;        // rows of the economized step polynomial [G][NT][KR_ECON_W] (Hermitian generators, Taylor method), or nullptr
     const double *nrm;         // [G][1 + L] 2-norm bounds
     const unsigned *present;   // [G] presence bits (L <= 32)
     const double *eps;         // [L][NT] pulses of this sweep (known) / guess pulses (update)

@@ -110,7 +110,7 @@ __device__ __forceinline__ void kr_gen_matvec(const KrGenArgs &a, const double2 
 template <int KTG>
 __device__ __forceinline__ void kr_gen_propagate(const KrGenArgs &a, const double2 *Hb, const int nmat, const double *c,
                                                  const double theta, const double sdt, const int step, double2 *psi, double2 *y0,
-                                                 double2 *y1, double2 *y2, double2 *red) {
+                                                 double2 *y1, double2 *y2, double2 *red, const int gen = 0) {
     const int tot = KTG * a.N;
     if (a.method == KR_METHOD_CHEBY || a.method == KR_METHOD_NEWTON) {
         const double *tab = a.ptab + (size_t)step * a.ptab_stride;
@@ -172,15 +172,23 @@ __device__ __forceinline__ void kr_gen_propagate(const KrGenArgs &a, const doubl
     }
     int s, m;
     kr_gen_plan(a, theta, s, m);
+    // economized step polynomial (kr_device.h: KrEcon; Hermitian generators): the step's row where it covers theta and saves a degree
+    const double *row = a.econ ? a.econ + ((size_t)gen * a.NT + step) * KR_ECON_W : nullptr;
+    bool eco = false;
+    if (row) {
+        const int me = (int)row[31];
+        if (me > 0 && theta <= row[30] && (s > 1 || me < m)) { eco = true; s = 1; m = me; }
+    }
     const double fs = (s == 1) ? sdt : sdt / (double)s;
     for (int sub = 0; sub < s; ++sub) {
         const double2 *src = psi;
-        for (int j = m; j >= 1; --j) {   // y <- psi + (-i fs / j) H y
+        for (int j = m; j >= 1; --j) {   // y <- psi + (-i fs g_j) H y  (g_j = 1 / j; economized: a_j / a_j-1, last round a_0 psi + a_1 z y_1)
             kr_gen_matvec<KTG>(a, Hb, nmat, c, src, y1, red);
-            const double f = fs * kr_rinv[j];
+            const double f = fs * (eco ? row[j] : kr_rinv[j]);
+            const double c0 = (eco && j == 1) ? row[0] : 1.0;
             for (int e = threadIdx.x; e < tot; e += blockDim.x) {
                 const double2 hv = y1[e], p = psi[e];
-                y0[e] = make_double2(fma(f, hv.y, p.x), fma(-f, hv.x, p.y));
+                y0[e] = make_double2(fma(f, hv.y, c0 * p.x), fma(-f, hv.x, c0 * p.y));
             }
             __syncthreads();
             src = y0;
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256) void kr_gen_known(const KrGenArgs a) {
         double theta = a.nrm[(size_t)gen * (1 + L)];
         c[0] = 1.0;
         for (int l = 0; l < L; ++l) { c[1 + l] = kr_gen_f(a, l, a.eps[(size_t)l * NT + n]); theta += fabs(c[1 + l]) * a.nrm[(size_t)gen * (1 + L) + 1 + l]; }
-        kr_gen_propagate<KTG>(a, Hb, 1 + L, c, theta * fabs(sdt), sdt, n, psi, y0, y1, y2, red);
+        kr_gen_propagate<KTG>(a, Hb, 1 + L, c, theta * fabs(sdt), sdt, n, psi, y0, y1, y2, red, gen);
         if (a.store) {
             const int slot = (a.dir > 0) ? (n + 1) : n;
             for (int e = threadIdx.x; e < tot; e += blockDim.x) a.store[(size_t)slot * slab + tb + e] = psi[e];
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(256) void kr_gen_apply(const KrGenArgs a) {
     double theta = a.nrm[(size_t)gen * (1 + L)];
     for (int l = 0; l < L; ++l) theta += fabs(kr_gen_f(a, l, a.eps_new[(size_t)l * NT + n])) * a.nrm[(size_t)gen * (1 + L) + 1 + l];
     const double one = 1.0, dtn = a.dt[n];
-    kr_gen_propagate<KTG>(a, a.Heps + (size_t)gen * N * N, 1, &one, theta * fabs(dtn), dtn, n, psi, y0, y1, y2, red);
+    kr_gen_propagate<KTG>(a, a.Heps + (size_t)gen * N * N, 1, &one, theta * fabs(dtn), dtn, n, psi, y0, y1, y2, red, gen);
     for (int e = threadIdx.x; e < tot; e += blockDim.x) {
         a.state[tb + e] = psi[e];
         if (a.store) a.store[(size_t)(n + 1) * slab + tb + e] = psi[e];

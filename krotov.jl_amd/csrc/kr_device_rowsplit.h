@@ -36,8 +36,12 @@ struct KrGeomR {
     // NR = NP = 128 (round 3): R = 1, the whole trajectory in ONE workgroup -- no all-gather, but the same resident H(eps) (half of it
     // in LDS, as at NR = 64 / NP = 256) and the same one or two streamed passes per STEP instead of the streamed-generator kernels'
     // (1 + L) matrices per ROUND: N = 128 with 129..256 trajectories
-    static_assert(NR == 8 || NR == 16 || NR == 32 || NR == 64 || (NR == 128 && NP == 128), "NR in {8,16,32,64} (128 at NP = 128)");
-    static_assert(NP == 128 || NP == 256, "NP in {128,256}");
+    // NP = 512 (round 3): 256 < N <= 512 with K * R <= #CUs, R = 32 / 64 workgroups per trajectory (NR = 16 / 8 rows each: 64 / 32
+    // registers for the H(eps) block); the all-gather is polled by two waves.  NP = 1024: R = 128 (8 rows each, 64 registers), four
+    // polling waves, at most two trajectories.
+    static_assert((NR == 8 && NP <= 1024) || (NR == 16 && NP <= 512) || ((NR == 32 || NR == 64) && NP <= 256) || (NR == 128 && NP == 128),
+                  "NR in {8,16,32,64} (128 at NP = 128; <= 16 at NP = 512; 8 at NP = 1024)");
+    static_assert(NP == 128 || NP == 256 || NP == 512 || NP == 1024, "NP in {128,256,512,1024}");
     static_assert(JS >= 2, "at least two columns per thread");
 };
 
@@ -112,15 +116,20 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
     // wave 0 gathers the NP - NR foreign elements: lane handles elements lane, lane + 64, ...; every load of a pass
     // is in flight before the first tag is looked at (no workgroup barrier inside the spin); 16-byte sc1 loads, the
     // loads of a pass and their wait in one asm block (KrPoll, kr_device.h)
+    // (more than 256 foreign elements, NP = 512: windows of 256 elements, window w polled by wave 0 (w = 0) / wave w + 1 -- wave 1
+    // publishes --, each with its own bounded spin; the verdicts meet in sflag[par * 8 + w])
     bool alive = true;
-    if ((tid >> 6) == 0) {
-        constexpr int EC = (NP - NR + 63) / 64;
-        static_assert(EC <= KR_POLL_CHUNKS, "at most 256 foreign elements");
+    constexpr int NWIN = (NP - NR + 255) / 256;
+    static_assert(NWIN <= 7, "one polling wave per window of 256 foreign elements");
+    const int pwin = ((tid >> 6) == 0) ? 0 : (tid >> 6) - 1;
+    if ((tid >> 6) != 1 && pwin < NWIN) {
+        constexpr int EC = (NWIN == 1) ? (NP - NR + 63) / 64 : KR_POLL_CHUNKS;
+        static_assert(EC <= KR_POLL_CHUNKS, "at most 256 foreign elements per window");
         const int lane = tid & 63;
         int el[KR_POLL_CHUNKS];
 #pragma unroll
         for (int c = 0; c < KR_POLL_CHUNKS; ++c) {
-            int q = min(lane + 64 * c, NP - NR - 1);
+            int q = min(pwin * 256 + lane + 64 * c, NP - NR - 1);
             if (q >= rb * NR) q += NR;
             el[c] = q;
         }
@@ -154,17 +163,19 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
         if (alive) {
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
-                if (lane + 64 * c < NP - NR) {
+                if (pwin * 256 + lane + 64 * c < NP - NR) {
                     const double re = __longlong_as_double((long long)(((unsigned long long)g[c].y << 32) | g[c].x));
                     const double im = __longlong_as_double((long long)(((unsigned long long)g[c].w << 32) | g[c].z));
                     dst[el[c] + el[c] / JS] = make_double2(re, im);
                 }
             }
         }
-        if (lane == 0) sflag[par] = alive ? 0 : 1;   // two slots by parity: the next gather writes the other one
+        if (lane == 0) sflag[par * 8 + pwin] = alive ? 0 : 1;   // two sets of slots by parity: the next gather writes the other one
     }
     __syncthreads();
-    const bool dead = (sflag[par] != 0);
+    bool dead = false;
+#pragma unroll
+    for (int w = 0; w < NWIN; ++w) dead = dead || (sflag[par * 8 + w] != 0);
     return !dead;
 }
 
@@ -288,7 +299,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     constexpr int XL = (LMAX < 2) ? 2 : LMAX;   // slot width of the per-step exchange (kr_exchange: 2 or 4 doubles)
     __shared__ double spart[XL * NR];
     __shared__ double stot[XL + 1];
-    __shared__ int sflag[2];
+    __shared__ int sflag[16];   // [parity][polling wave] (kr_group_gather)
 
     // Workgroup -> (trajectory tile, row block).  With a.xcd_group (K % 8 == 0) the R workgroups of a tile have equal
     // blockIdx % 8: one XCD under the dispatcher's round-robin placement, which is CHECKED below through HW_REG_XCC_ID;
@@ -495,9 +506,16 @@ static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hi
         return hipGetLastError();                                                                      \
     }
     if constexpr (NP == 128) { KR_CASE_R(1, 128) KR_CASE_R(2, 128) }   // R = 1: one workgroup per trajectory (L <= 2: LMAX = 4 spills)
+    if constexpr (NP == 1024) {  // 512 < N <= 1024: 8 rows per workgroup (128 workgroups per trajectory), one or two controls
+        KR_CASE_R(1, 8) KR_CASE_R(2, 8)
+    } else if constexpr (NP == 512) {   // 256 < N <= 512: 8 or 16 rows per workgroup, one or two controls
+        KR_CASE_R(1, 8) KR_CASE_R(1, 16)     // (NR = 32: the LDS half of the block + the vectors exceed 160 KB)
+        KR_CASE_R(2, 8) KR_CASE_R(2, 16)
+    } else {
     KR_CASE_R(1, 8) KR_CASE_R(1, 16) KR_CASE_R(1, 32) KR_CASE_R(1, 64)   // one control: C5's shape
     KR_CASE_R(2, 8) KR_CASE_R(2, 16) KR_CASE_R(2, 32) KR_CASE_R(2, 64)
     KR_CASE_R(4, 8) KR_CASE_R(4, 16) KR_CASE_R(4, 32) KR_CASE_R(4, 64)
+    }
 #undef KR_CASE_R
     return hipErrorInvalidValue;
 }

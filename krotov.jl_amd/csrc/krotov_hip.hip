@@ -86,6 +86,7 @@ struct kr_handle {
     bool herm = false;    // every control operator Hermitian: update kernel variant HERM (kr_device.h)
     bool econ = false;    // every generator Hermitian (drift and control operators): economized step polynomial in the update sweep
     double *econ_d = nullptr;   // [G][NT][KR_ECON_W] rows, rewritten from the guess pulses in front of every update sweep
+    bool econ_gen = false;      // generic (multi-pass) kernels, Taylor method, every generator Hermitian: economized polynomial there too
     double *skw_d = nullptr;    // [G][1 + KR_LMAX_CAP] 2-norm bounds of the anti-Hermitian parts (pair mode with a generator that is not Hermitian), or nullptr
     int poll_delay = -1;  // exchange schedule of the update sweep (KrSweepArgs::poll_delay), set by calibrate_exchange
     unsigned long long *peer_xmail[8]{};
@@ -268,7 +269,7 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
 static const char *const kr_option_names[] = {
     "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
     "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "POLL_DELAY", "PRECOMP", "ROWSPLIT",
-    "RS_LMAX1", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
+    "RS512", "RS_LMAX1", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
 static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
     out.clear();
     if (!text) return true;
@@ -314,26 +315,28 @@ static int opt_int(const kr_handle *h, const char *name, int dflt);
 // the rectangle's corner, |T_k| <= (rho^k + rho^-k) / 2, and ||p(A) - f(A)|| <= (1 + sqrt 2) max over the numerical range of |p - f|
 // (Crouzeix-Palencia), so the degree is the smallest m with (1 + sqrt 2) sum_{k>m} |c_k| (rho^k + rho^-k) / 2 <= tol.  C5's
 // Liouvillian (theta 0.09, beta 0.006, rho 1.3): degree 8 against Taylor's 9.  A row that saves nothing is not written.
+// `nstride`: doubles per generator in nrm / skw (1 + KR_LMAX_CAP for the persistent kernels' table, 1 + L for the generic kernels');
+// L: controls to sum over (the caller caps it at what the table holds).
 __global__ __launch_bounds__(64) void kr_econ_rows_kernel(const double *eps, const double *dt, const double *nrm, const double *skw, int G, int NT, int L,
-                                                           double tol, double margin, double *rows) {
+                                                           int nstride, double tol, double margin, double *rows) {
     __shared__ double c[64];
     const int idx = blockIdx.x, lane = threadIdx.x;
     if (idx >= G * NT) return;
     const int g = idx / NT, n = idx % NT;
     double *row = rows + (size_t)idx * KR_ECON_W;
-    double th = nrm[(size_t)g * (1 + KR_LMAX_CAP)];
-    for (int l = 0; l < L && l < KR_LMAX_CAP; ++l) th += fabs(eps[(size_t)l * NT + n]) * nrm[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l];
+    double th = nrm[(size_t)g * nstride];
+    for (int l = 0; l < L; ++l) th += fabs(eps[(size_t)l * NT + n]) * nrm[(size_t)g * nstride + 1 + l];
     double beta = 0.0;
     if (skw) {
-        const double n0 = nrm[(size_t)g * (1 + KR_LMAX_CAP)];
+        const double n0 = nrm[(size_t)g * nstride];
         double ratio = 0.0, ctl = 0.0;
         bool unbounded = false;
-        for (int l = 0; l < L && l < KR_LMAX_CAP; ++l) {
-            const double nl = nrm[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l], sl = skw[(size_t)g * (1 + KR_LMAX_CAP) + 1 + l];
+        for (int l = 0; l < L; ++l) {
+            const double nl = nrm[(size_t)g * nstride + 1 + l], sl = skw[(size_t)g * nstride + 1 + l];
             ctl += fabs(eps[(size_t)l * NT + n]) * nl;
             if (sl > 0.0) { if (nl > 0.0) ratio = fmax(ratio, sl / nl); else unbounded = true; }
         }
-        beta = skw[(size_t)g * (1 + KR_LMAX_CAP)] + ratio * (margin * ctl + (margin - 1.0) * n0);
+        beta = skw[(size_t)g * nstride] + ratio * (margin * ctl + (margin - 1.0) * n0);
         beta *= fabs(dt[n]);
         if (unbounded) th = 0.0;   // (cannot happen: the 2-norm bound of an operator is not below that of its anti-Hermitian part)
     }
@@ -520,7 +523,8 @@ static const char *kr_rccl_why() { (void)kr_rccl(); return g_rccl.why.empty() ? 
 // ---- plan -------------------------------------------------------------------------------------
 static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen, int maxwg_cfg) {
     const kr_config &c = h->cfg;
-    if (c.N > 256) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 256 is not supported by this build", c.N);
+    if (c.N > 1024) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 1024 is not supported by the persistent kernels", c.N);
+    if (c.N > 256 && (c.L > 2 || opt_int(h, "RS512", 1) == 0)) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 256 with L = %d: no persistent kernel", c.N, c.L);
     if (c.L > KR_LMAX_CAP) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > %d controls not supported by this build", c.L, KR_LMAX_CAP);
     int NP = 8;
     while (NP < c.N) NP <<= 1;
@@ -555,7 +559,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
     if (maxwg < 1) maxwg = 1;
     if (NP > 64 && opt_int(h, "ROWSPLIT", 1) != 0) {
         // R workgroups per trajectory, NR = NP / R rows each (8 <= NR <= 64: the H(eps) block must fit the registers)
-        int R = NP / 64;
+        int R = (NP == 1024) ? 128 : (NP == 512) ? 32 : NP / 64;   // (NP = 512 / 1024, round 3: at most 16 / 8 rows per workgroup -- the block of H(eps) stays in 64 registers)
         // N = 256, one control, shared generator, more pairs than groups of 8 workgroups: the groups carry up to 4 pairs each in turn
         // (round 3: kr_rowsplit_pair_sweep<.., MULTI>; before: the streamed-generator kernels, 8 x the time per trajectory)
         int rs_sets = 1;
@@ -592,7 +596,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             h->JS = NP / h->JQ;
             h->RT = h->threads;
             h->SG = 1;
-            h->launch_rs = (NP == 128) ? kr_launch_rs128 : kr_launch_rs256;
+            h->launch_rs = (NP == 128) ? kr_launch_rs128 : (NP == 512) ? kr_launch_rs512 : (NP == 1024) ? kr_launch_rs1024 : kr_launch_rs256;
             h->KT = h->rs_pair ? 2 : 1;
             h->KTILE = h->KT;
             h->Kp = ((c.K + h->KT - 1) / h->KT) * h->KT;   // pair mode: padded to an even count
@@ -609,6 +613,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             return KR_OK;
         }
     }
+    if (NP > 256) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 256 with %d trajectories: more than the row-split kernels carry (K x %d workgroups <= %d)", c.N, c.K, NP == 1024 ? 128 : 32, maxwg);
     int kt = opt_int(h, "KT", 0);
     if (kt != 0 && kt != 1 && kt != 2 && kt != 4) return fail(h, KR_ERR_INVALID, "KROTOV_HIP_KT must be 1, 2 or 4");
     // trajectories per generator (tiles never mix generators)
@@ -1027,7 +1032,20 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         }
     }
     if (econ_pair) h->econ = true;
-    if (h->econ) {
+    // generic (multi-pass) kernels: Hermitian generators only (entry by entry), Taylor method, linear controls
+    if (opt_int(h, "ECON", 1) != 0 && (h->gen_known || h->gen_update) && (h->method == KR_PROP_AUTO || h->method == KR_PROP_TAYLOR) && h->poly_deg == 0) {
+        bool herm_all = true;
+        for (int g = 0; g < G && herm_all; ++g)
+            for (int m = 0; m <= L && herm_all; ++m) {
+                if (m > 0 && L <= 32 && !((present[g] >> (m - 1)) & 1u)) continue;
+                const zc *M = (m == 0) ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn;
+                for (int c = 0; c < N && herm_all; ++c)
+                    for (int r = 0; r <= c; ++r)
+                        if (M[(size_t)c * N + r] != std::conj(M[(size_t)r * N + c])) { herm_all = false; break; }
+            }
+        h->econ_gen = herm_all;
+    }
+    if (h->econ || h->econ_gen) {
         CHK(dalloc(&h->econ_d, (size_t)G * NT * KR_ECON_W));
         CHK(hipMemset(h->econ_d, 0, (size_t)G * NT * KR_ECON_W * sizeof(double)));
     }
@@ -1275,7 +1293,7 @@ static int one_get_info(kr_handle *h, int32_t *info) {
     if (!h || !info) return KR_ERR_INVALID;
     memset(info, 0, 16 * sizeof(int32_t));
     info[0] = h->NP; info[1] = h->P; info[2] = h->KTILE; info[3] = h->threads; info[4] = h->KT;
-    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay; info[12] = (h->herm && h->NP <= 64) ? 1 : 0; info[13] = h->mfma_sweep ? 1 : 0; info[14] = h->gen_known ? 1 : 0; info[15] = (h->gen_update ? 1 : 0) | (h->exchange << 4) | (h->econ ? 256 : 0);
+    info[5] = h->LMAXv; info[6] = h->Kp; info[7] = h->store_fw ? 1 : 0; info[8] = h->JQ; info[9] = h->precomp ? 1 : 0; info[10] = h->rowsplit ? h->R : 0; info[11] = h->poll_delay; info[12] = (h->herm && h->NP <= 64) ? 1 : 0; info[13] = h->mfma_sweep ? 1 : 0; info[14] = h->gen_known ? 1 : 0; info[15] = (h->gen_update ? 1 : 0) | (h->exchange << 4) | ((h->econ || h->econ_gen) ? 256 : 0);
     if (h->mfma_sweep) info[3] = 256;
     // Taylor plan at zero pulse amplitude (drift only) for the mean step, for reporting
     return KR_OK;
@@ -1500,6 +1518,7 @@ static void gen_args(kr_handle *h, KrGenArgs &g) {
     g.N = h->cfg.N; g.NT = h->cfg.NT; g.Kp = h->Kp; g.L = h->cfg.L; g.G = h->G;
     g.KTG = h->KTG; g.RP = h->RP; g.JQ = h->JQg; g.tiles = h->gen_tiles;
     g.poly = h->poly_d; g.poly_deg = h->poly_deg;
+    g.econ = nullptr;
     g.method = h->method; g.ptab = h->ptab_d; g.ptab_stride = h->ptab_stride; g.erange = nullptr; g.status = h->status_d;
 }
 
@@ -1511,6 +1530,12 @@ static int launch_known_generic(kr_handle *h, const double *eps_dev, bool backwa
     g.init = init; g.store = store; g.fin = fin;
     g.dir = backward ? -1 : +1;
     if (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON) { const int rc = build_poly_tables(h, eps_dev, 1.0); if (rc) return rc; }
+    if (h->econ_gen) {   // economized polynomial of every step (pulses known exactly: the margin covers rounding only)
+        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(h->G * h->cfg.NT), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_gen_d, (const double *)nullptr, h->G,
+                           h->cfg.NT, h->cfg.L, 1 + h->cfg.L, h->tol, 1.0 + 1e-9, h->econ_d);
+        HIPCHK(h, hipGetLastError());
+        g.econ = h->econ_d;
+    }
     HIPCHK(h, kr_launch_generic(0, h->KTG, h->gen_tiles, h->gen_lds, h->stream, &g));
     return KR_OK;
 }
@@ -1540,6 +1565,12 @@ static int launch_update_stepped(kr_handle *h, const double *eps_guess_dev, doub
         const int rc = build_poly_tables(h, eps_guess_dev, 5.0);
         if (rc) return rc;
         g.erange = h->erange_d;
+    }
+    if (h->econ_gen) {   // rows from the guess pulses, 1 % margin (a step whose updated pulse leaves it takes Taylor's plan)
+        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(h->G * NT), dim3(64), 0, h->stream, eps_guess_dev, h->dt_d, h->nrm_gen_d, (const double *)nullptr, h->G, NT, L,
+                           1 + L, h->tol, 1.01, h->econ_d);
+        HIPCHK(h, hipGetLastError());
+        g.econ = h->econ_d;
     }
     HIPCHK(h, hipMemcpyAsync(h->psiT_d, h->psi0_d, slab * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
     if (h->store_fw) HIPCHK(h, hipMemcpyAsync(h->Phi_d, h->psi0_d, slab * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
@@ -1597,7 +1628,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         if (rc) return rc;
         if (h->econ) {   // economized polynomial of every step (pulses known exactly: the margin covers rounding only)
             hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(h->G * h->cfg.NT), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT,
-                               h->cfg.L, h->tol, 1.0 + 1e-9, h->econ_d);
+                               std::min(h->cfg.L, KR_LMAX_CAP), 1 + KR_LMAX_CAP, h->tol, 1.0 + 1e-9, h->econ_d);
             HIPCHK(h, hipGetLastError());
             a.econ = h->econ_d;
         }
@@ -1616,7 +1647,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         if (h->econ && h->NP == 64) {   // economized polynomial of every step (the pulses are known exactly: margin = rounding only;
                                         // smaller N: building the rows costs what the saved product gains -- C2 +6 us per sweep)
             const int rows = h->G * h->cfg.NT;
-            hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT, h->cfg.L,
+            hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT, std::min(h->cfg.L, KR_LMAX_CAP), 1 + KR_LMAX_CAP,
                                h->tol, 1.0 + 1e-9, h->econ_d);
             HIPCHK(h, hipGetLastError());
             a.econ = h->econ_d;
@@ -1649,7 +1680,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         a.gen_div = h->KT * h->sets / kt_known;
         if (h->econ && h->NP > 64) {   // streamed-generator kernels: economized polynomial of every step (margin: rounding only)
             hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(h->G * h->cfg.NT), dim3(64), 0, h->stream, eps_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT,
-                               h->cfg.L, h->tol, 1.0 + 1e-9, h->econ_d);
+                               std::min(h->cfg.L, KR_LMAX_CAP), 1 + KR_LMAX_CAP, h->tol, 1.0 + 1e-9, h->econ_d);
             HIPCHK(h, hipGetLastError());
             a.econ = h->econ_d;
         }
@@ -1682,7 +1713,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
     if (h->econ) {   // rows of the economized step polynomial from this sweep's guess pulses (device-resident pulses included)
         const int rows = h->G * h->cfg.NT;
-        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_guess_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT, h->cfg.L,
+        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_guess_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT, std::min(h->cfg.L, KR_LMAX_CAP), 1 + KR_LMAX_CAP,
                            h->tol, 1.01, h->econ_d);
         HIPCHK(h, hipGetLastError());
         a.econ = h->econ_d;

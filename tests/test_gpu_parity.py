@@ -285,14 +285,14 @@ def test_rowsplit_with_substeps_and_generators(oracle_c):
 
 def test_unsupported_sizes_fail_loudly(monkeypatch):
     """What no kernel of this build carries fails with KR_ERR_UNSUPPORTED and a message: more than 32 controls; with the
-    generic fallback forbidden (KROTOV_HIP_GENERIC=0) also N > 256."""
+    generic fallback forbidden (KROTOV_HIP_GENERIC=0) also N > 1024 (round 3: the row-split kernels carry N <= 1024)."""
     with pytest.raises(kr.KrotovHipError) as ei:
         kr.HipEngine(np.eye(4), np.tile(np.eye(4), (33, 1, 1)), np.linspace(0, 1, 3), 1)
     assert ei.value.code == kr._capi.KR_ERR_UNSUPPORTED
     monkeypatch.setenv("KROTOV_HIP_GENERIC", "0")
     with pytest.raises(kr.KrotovHipError) as ei:
-        kr.HipEngine(np.eye(300), np.eye(300)[None], np.linspace(0, 1, 3), 1)
-    assert ei.value.code == kr._capi.KR_ERR_UNSUPPORTED and "N = 300" in str(ei.value)
+        kr.HipEngine(np.eye(1100), np.eye(1100)[None], np.linspace(0, 1, 3), 1)
+    assert ei.value.code == kr._capi.KR_ERR_UNSUPPORTED and "N = 1100" in str(ei.value)
 
 
 @pytest.mark.parametrize("herm", ["0", "2"])

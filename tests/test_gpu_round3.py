@@ -496,3 +496,51 @@ def test_options_travel_in_kr_config(monkeypatch):
         with pytest.raises(Exception) as ei:
             plan(options=bad)
         assert "options" in str(ei.value) and bad in str(ei.value)
+
+
+@pytest.mark.parametrize("N,NT,K,L,R", [(300, 6, 3, 1, 64), (400, 5, 8, 2, 32), (512, 5, 2, 1, 64), (260, 40, 4, 2, 64)])
+def test_state_dimension_up_to_512_on_the_rowsplit_kernels(oracle_c, N, NT, K, L, R):
+    """256 < N <= 512 (round 3): the single-mode row-split kernels with NP = 512 -- 64 or 32 workgroups per trajectory, 8 or 16 rows
+    each, the all-gather polled by two waves -- instead of the generic multi-pass kernels (N = 512, K = 4: 14.6 / 19 us per step
+    against 6.3 / 1.6 ms), for up to 8 trajectories.  All three sweeps against the oracle; the last case non-Hermitian, across a
+    rebuild of the H(eps) block."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_parity as tp
+    p = wl.dense_problem(N, NT, K, L, 7700 + N, 0.02, 2.0)
+    if N == 260:
+        p["H0"] = p["H0"] - 0.01j * np.diag(np.random.default_rng(3).uniform(0, 1, N))
+    info = tp._run_case(oracle_c, p, check_storage=(N == 300))
+    assert info["NP"] == 512 and info["rowsplit_R"] == R and info["workgroups"] == K * R, info
+    assert info["generic_known"] == 0 and info["generic_update"] == 0, info
+
+
+def test_state_dimension_above_256_with_many_trajectories_takes_the_generic_kernels(oracle_c):
+    """More trajectories than the NP = 512 row-split plan carries (K x 32 workgroups > #CUs), or more than two controls: the
+    generic multi-pass kernels, as before -- same results."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_parity as tp
+    for (N, NT, K, L) in [(264, 4, 9, 1), (258, 4, 2, 3)]:
+        p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
+        info = tp._run_case(oracle_c, p, check_storage=False)
+        assert info["generic_known"] == 1 and info["generic_update"] == 1, info
+
+
+@pytest.mark.parametrize("N,NT,K,L", [(640, 4, 2, 1), (1024, 3, 1, 2), (520, 36, 2, 2)])
+def test_state_dimension_up_to_1024_on_the_rowsplit_kernels(N, NT, K, L):
+    """512 < N <= 1024 (round 3): NP = 1024, 128 workgroups per trajectory with 8 rows each, four polling waves in the all-gather, at
+    most two trajectories.  Against the serial restatement on the NumPy oracle's exact step propagator (the C oracle's plain-loop
+    Pade would take minutes at this size); the last case across a rebuild of the H(eps) block."""
+    import krotov_oracle as o
+    p = wl.dense_problem(N, NT, K, L, 7900 + N, 0.02, 2.0)
+    H0, Hc = p["H0"][None], p["Hc"][None]
+    tg = np.zeros(K, np.int32)
+    psiT_o, chiT, eps_o, ga_o, psi1_o = _serial_iteration(o, H0, Hc, np.ones((1, L), np.uint8), tg, p["tlist"], p["eps"], p["S"], p["lam"],
+                                                          p["psi0"], p["tgt"])
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        info = eng.info()
+        assert info["NP"] == 1024 and info["rowsplit_R"] == 128 and info["workgroups"] == 128 * K and info["generic_update"] == 0, eng.plan()
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        assert np.max(np.abs(psiT - psiT_o)) < TOL_STATE
+        eps_new, ga, psiT1 = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+    assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < TOL_GA and np.max(np.abs(psiT1 - psi1_o)) < TOL_STATE
