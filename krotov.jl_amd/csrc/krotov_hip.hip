@@ -206,7 +206,11 @@ static double norm2_bound(int n, const zc *A) {
     for (int i = 0; i < n; ++i) x[i] = zc(1.0 + 0.37 * std::sin(1.7 * i + 0.3), 0.21 * std::cos(2.3 * i));
     double sigma = 0;
     bool converged = false;
-    for (int it = 0; it < 2000; ++it) {
+    // (n > 256: 400 iterations -- each is two products with an n x n matrix on the host, 2000 of them cost seconds at n = 1024;
+    //  an estimate that has not settled by then takes the 5 % margin below, the Rayleigh quotient's error after k iterations
+    //  falls like (sigma_2 / sigma_1)^(4k))
+    const int max_it = (n > 256) ? 400 : 2000;
+    for (int it = 0; it < max_it; ++it) {
         double nx = 0;
         for (int i = 0; i < n; ++i) nx += std::norm(x[i]);
         nx = std::sqrt(nx);
