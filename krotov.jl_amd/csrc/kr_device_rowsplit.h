@@ -511,6 +511,7 @@ static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hi
     } else if constexpr (NP == 512) {   // 256 < N <= 512: 8 or 16 rows per workgroup, one or two controls
         KR_CASE_R(1, 8) KR_CASE_R(1, 16)     // (NR = 32: the LDS half of the block + the vectors exceed 160 KB)
         KR_CASE_R(2, 8) KR_CASE_R(2, 16)
+        KR_CASE_R(4, 8)
     } else {
     KR_CASE_R(1, 8) KR_CASE_R(1, 16) KR_CASE_R(1, 32) KR_CASE_R(1, 64)   // one control: C5's shape
     KR_CASE_R(2, 8) KR_CASE_R(2, 16) KR_CASE_R(2, 32) KR_CASE_R(2, 64)

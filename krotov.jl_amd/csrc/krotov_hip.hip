@@ -528,7 +528,7 @@ static const char *kr_rccl_why() { (void)kr_rccl(); return g_rccl.why.empty() ? 
 static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_gen, int maxwg_cfg) {
     const kr_config &c = h->cfg;
     if (c.N > 1024) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 1024 is not supported by the persistent kernels", c.N);
-    if (c.N > 256 && (c.L > 2 || opt_int(h, "RS512", 1) == 0)) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 256 with L = %d: no persistent kernel", c.N, c.L);
+    if (c.N > 256 && (c.L > ((c.N <= 512) ? 4 : 2) || opt_int(h, "RS512", 1) == 0)) return fail(h, KR_ERR_UNSUPPORTED, "N = %d > 256 with L = %d: no persistent kernel", c.N, c.L);
     if (c.L > KR_LMAX_CAP) return fail(h, KR_ERR_UNSUPPORTED, "L = %d > %d controls not supported by this build", c.L, KR_LMAX_CAP);
     int NP = 8;
     while (NP < c.N) NP <<= 1;
@@ -563,7 +563,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
     if (maxwg < 1) maxwg = 1;
     if (NP > 64 && opt_int(h, "ROWSPLIT", 1) != 0) {
         // R workgroups per trajectory, NR = NP / R rows each (8 <= NR <= 64: the H(eps) block must fit the registers)
-        int R = (NP == 1024) ? 128 : (NP == 512) ? 32 : NP / 64;   // (NP = 512 / 1024, round 3: at most 16 / 8 rows per workgroup -- the block of H(eps) stays in 64 registers)
+        int R = (NP == 1024) ? 128 : (NP == 512) ? ((c.L > 2) ? 64 : 32) : NP / 64;   // (three or four controls at NP = 512: 8 rows per workgroup only)   // (NP = 512 / 1024, round 3: at most 16 / 8 rows per workgroup -- the block of H(eps) stays in 64 registers)
         // N = 256, one control, shared generator, more pairs than groups of 8 workgroups: the groups carry up to 4 pairs each in turn
         // (round 3: kr_rowsplit_pair_sweep<.., MULTI>; before: the streamed-generator kernels, 8 x the time per trajectory)
         int rs_sets = 1;

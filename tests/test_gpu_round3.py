@@ -498,7 +498,7 @@ def test_options_travel_in_kr_config(monkeypatch):
         assert "options" in str(ei.value) and bad in str(ei.value)
 
 
-@pytest.mark.parametrize("N,NT,K,L,R", [(300, 6, 3, 1, 64), (400, 5, 8, 2, 32), (512, 5, 2, 1, 64), (260, 40, 4, 2, 64)])
+@pytest.mark.parametrize("N,NT,K,L,R", [(300, 6, 3, 1, 64), (400, 5, 8, 2, 32), (512, 5, 2, 1, 64), (260, 40, 4, 2, 64), (280, 5, 3, 4, 64)])
 def test_state_dimension_up_to_512_on_the_rowsplit_kernels(oracle_c, N, NT, K, L, R):
     """256 < N <= 512 (round 3): the single-mode row-split kernels with NP = 512 -- 64 or 32 workgroups per trajectory, 8 or 16 rows
     each, the all-gather polled by two waves -- instead of the generic multi-pass kernels (N = 512, K = 4: 14.6 / 19 us per step
@@ -515,11 +515,11 @@ def test_state_dimension_up_to_512_on_the_rowsplit_kernels(oracle_c, N, NT, K, L
 
 
 def test_state_dimension_above_256_with_many_trajectories_takes_the_generic_kernels(oracle_c):
-    """More trajectories than the NP = 512 row-split plan carries (K x 32 workgroups > #CUs), or more than two controls: the
-    generic multi-pass kernels, as before -- same results."""
+    """More trajectories than the NP = 512 row-split plan carries (K x 32 workgroups > #CUs; K x 64 with three or four controls), or
+    more than two controls beyond N = 512: the generic multi-pass kernels, as before -- same results."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_gpu_parity as tp
-    for (N, NT, K, L) in [(264, 4, 9, 1), (258, 4, 2, 3)]:
+    for (N, NT, K, L) in [(264, 4, 9, 1), (258, 4, 5, 3), (600, 3, 1, 3)]:
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=False)
         assert info["generic_known"] == 1 and info["generic_update"] == 1, info
