@@ -51,6 +51,9 @@ struct kr_handle {
     bool rowsplit = false;
     int rs_sets = 1;           // pair mode: pairs per group of workgroups, in turn (kr_rowsplit_pair_sweep<.., MULTI>)
     double2 *rs_scratch_d = nullptr;
+    int rs_batch = 0;          // > 0: N > 256 with more trajectories than one row-split launch carries -- the KNOWN-pulse sweeps run the
+                               // row-split kernel in batches of rs_batch trajectories (independent launches), the update sweep is the stepped
+                               // generic one (its per-step sum needs every trajectory)
     bool rs_pair = false;      // row-split PAIR mode (kr_device_rowsplit2.h): R workgroups share two trajectories and interleave them
     int R = 1, NR = 0;
     kr_launch_fn launch_rs = nullptr;
@@ -273,7 +276,7 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
 static const char *const kr_option_names[] = {
     "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
     "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "POLL_DELAY", "PRECOMP", "ROWSPLIT",
-    "RS512", "RS_LMAX1", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
+    "RS512", "RS_BATCH", "RS_LMAX1", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
 static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
     out.clear();
     if (!text) return true;
@@ -577,8 +580,11 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
         // (round 3; before: the streamed-generator kernels, (1 + L) matrices per ROUND -- 39 us per step against ~10)
         // (L <= 2: the four-control instantiation spills 2 KB per thread and loses to the streamed-generator kernels)
         if (NP == 128 && c.L <= 2 && (long long)c.K * R > maxwg && c.K <= maxwg && opt_int(h, "RS_R1", 1) != 0) R = 1;
-        if (((long long)c.K * R <= maxwg || rs_sets > 1) && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
-            while (NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
+        int rs_batch = 0;
+        if (NP >= 512 && (long long)c.K * R > maxwg && R <= maxwg && opt_int(h, "RS_BATCH", 1) != 0) rs_batch = maxwg / R;
+        if (((long long)c.K * R <= maxwg || rs_sets > 1 || rs_batch > 0) && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
+            while (rs_batch == 0 && NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
+            h->rs_batch = rs_batch;
             h->rowsplit = true;
             if (c.L == 1 && opt_int(h, "RS_LMAX1", 1) != 0) h->LMAXv = 1;   // row-split kernels have an instantiation for ONE control (C5): fewer
                                                                                  // accumulators and chunk registers in the streaming passes
@@ -605,6 +611,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             h->KTILE = h->KT;
             h->Kp = ((c.K + h->KT - 1) / h->KT) * h->KT;   // pair mode: padded to an even count
             h->P = (h->Kp / h->KT) * R;
+            if (h->rs_batch > 0) h->P = std::min(c.K, h->rs_batch) * R;   // (one batch: the grid of a known-pulse launch)
             if (h->rs_sets > 1) {   // groups x sets pairs, zero trajectories behind the last real one
                 const int groups = maxwg / R;
                 h->Kp = 2 * groups * h->rs_sets;
@@ -796,12 +803,13 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
     if (!h->fast_ok && genv == 0 && !poly) return rc;
     // exchange
     int ex = c.exchange;
-    if (ex == KR_EXCHANGE_AUTO) ex = h->fast_ok ? KR_EXCHANGE_MAILBOX : (c.world > 1 ? KR_EXCHANGE_RCCL : KR_EXCHANGE_MAILBOX);
-    if (ex == KR_EXCHANGE_MAILBOX && !h->fast_ok && c.world > 1)
+    const bool update_fast = h->fast_ok && h->rs_batch == 0;   // (batched row-split plan: only the known-pulse sweeps are persistent)
+    if (ex == KR_EXCHANGE_AUTO) ex = update_fast ? KR_EXCHANGE_MAILBOX : (c.world > 1 ? KR_EXCHANGE_RCCL : KR_EXCHANGE_MAILBOX);
+    if (ex == KR_EXCHANGE_MAILBOX && !update_fast && c.world > 1)
         return fail(h, KR_ERR_UNSUPPORTED, "this problem runs on the generic kernels (%s); with world > 1 they need exchange = RCCL or CALLBACK", h->err.c_str());
     h->exchange = ex;
     h->gen_known = !h->fast_ok;
-    h->gen_update = !h->fast_ok || ex == KR_EXCHANGE_RCCL || ex == KR_EXCHANGE_CALLBACK;
+    h->gen_update = !update_fast || ex == KR_EXCHANGE_RCCL || ex == KR_EXCHANGE_CALLBACK;
     if (!h->gen_known && !h->gen_update) return KR_OK;
     if (h->fast_ok) {
         // stepped update sweep on the fast plan's trajectory layout: generic tiles subdivide its tiles
@@ -1636,6 +1644,20 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
             HIPCHK(h, hipGetLastError());
             a.econ = h->econ_d;
         }
+        if (h->rs_batch > 0) {   // batches of trajectories, one launch each (known-pulse sweeps: the trajectories are independent)
+            const int N = h->cfg.N, K = h->cfg.K;
+            for (int b0 = 0; b0 < K; b0 += h->rs_batch) {
+                const int nb = std::min(h->rs_batch, K - b0);
+                if (b0 > 0) { rc = rowsplit_prelaunch(h, a); if (rc) return rc; }
+                a.init = init + (size_t)b0 * N;
+                a.store = store ? store + (size_t)b0 * N : nullptr;
+                a.fin = fin ? fin + (size_t)b0 * N : nullptr;
+                a.wg_gen = (h->G > 1) ? h->wg_gen_d + b0 : nullptr;
+                a.P = nb * h->R;
+                a.xcd_group = (h->xcd_group && nb % 8 == 0) ? 1 : 0;
+                HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 0, nb * h->R, h->stream, &a));
+            }
+        } else
         HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 2 : 0, h->P, h->stream, &a));
     } else if (h->precomp) {
         // all N_T step propagators in parallel, then one matvec round per step.  N = 64: both on the matrix cores

@@ -62,8 +62,8 @@ def test_generic_kernels_forced_on_small_shapes(oracle_c, monkeypatch):
 def test_beyond_the_capacity_of_the_persistent_kernels(oracle_c):
     """N > 256, L > 4 and more trajectories than 256 co-resident workgroups can carry: no KR_ERR_UNSUPPORTED any more
     (the reference has no such limits, /root/reference/src/workspace.jl:128-161) -- the generic kernels take over."""
-    info = _check(oracle_c, wl.dense_problem(300, 3, 9, 1, 311, 0.02, 1.0), check_storage=False)   # (round 3: up to 8 trajectories at
-    assert info["generic_known"] == 1 and info["generic_update"] == 1                              #  256 < N <= 512 are persistent)
+    info = _check(oracle_c, wl.dense_problem(300, 3, 2, 5, 311, 0.02, 1.0), check_storage=False)   # (round 3: N <= 512 with up to four
+    assert info["generic_known"] == 1 and info["generic_update"] == 1                              #  controls runs on the row-split kernels)
     info = _check(oracle_c, wl.dense_problem(9, 10, 5, 6, 312, 0.1, 1.0))           # six controls
     assert info["generic_update"] == 1
     info = _check(oracle_c, wl.dense_problem(64, 3, 1100, 2, 313, 0.05, 5.0), check_storage=False)   # K = 1100 at N = 64

@@ -514,12 +514,18 @@ def test_state_dimension_up_to_512_on_the_rowsplit_kernels(oracle_c, N, NT, K, L
     assert info["generic_known"] == 0 and info["generic_update"] == 0, info
 
 
-def test_state_dimension_above_256_with_many_trajectories_takes_the_generic_kernels(oracle_c):
-    """More trajectories than the NP = 512 row-split plan carries (K x 32 workgroups > #CUs; K x 64 with three or four controls), or
-    more than two controls beyond N = 512: the generic multi-pass kernels, as before -- same results."""
+def test_state_dimension_above_256_with_more_trajectories(oracle_c):
+    """More trajectories than one NP = 512 / 1024 row-split launch carries: the KNOWN-pulse sweeps still run the row-split kernel, in
+    batches of trajectories (independent launches: N = 512, K = 32: 85 us per step against ~6 ms on the generic kernels), the update
+    sweep -- whose per-step sum needs every trajectory -- is the stepped generic one.  More than four controls (two beyond N = 512):
+    the generic kernels everywhere, as before.  Same results."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_gpu_parity as tp
-    for (N, NT, K, L) in [(264, 4, 9, 1), (258, 4, 5, 3), (600, 3, 1, 3)]:
+    for (N, NT, K, L) in [(300, 5, 20, 1), (264, 4, 9, 2), (520, 3, 3, 1)]:
+        p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
+        info = tp._run_case(oracle_c, p, check_storage=(N == 264))
+        assert info["generic_known"] == 0 and info["generic_update"] == 1 and info["rowsplit_R"] in (32, 128), info
+    for (N, NT, K, L) in [(258, 4, 3, 5), (600, 3, 1, 3)]:
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=False)
         assert info["generic_known"] == 1 and info["generic_update"] == 1, info
