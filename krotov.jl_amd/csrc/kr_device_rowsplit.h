@@ -1,4 +1,5 @@
-// Row-split sweep kernels for 64 < N <= 256 (NP in {128, 256}): R workgroups share ONE trajectory.
+// Row-split sweep kernels for 64 < N <= 1024 (NP in {128, 256}; round 3: also 512 and 1024 for few trajectories): R workgroups
+// share ONE trajectory.
 //
 // With K < #CUs and N large, one workgroup per trajectory leaves most of the chip idle and has to stream the
 // whole generator (N = 256: 1 MB per matrix) from L2 for every matvec round (kr_device_stream.h: 16 us per
