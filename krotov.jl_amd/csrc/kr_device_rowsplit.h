@@ -497,6 +497,223 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     }
 }
 
+// =============================================================================================
+// Update sweep IN TURNS (round 3, NP >= 512): more trajectories than groups of R workgroups -- every group carries a.rs_sets
+// trajectories, set s = trajectory s * groups + group.  The H(eps) block is resident once and serves every set (shared generator).
+// Per step: phase A of every set in turn (its vector from the workgroup's global scratch into LDS, one streamed pass over the
+// control blocks for b = H(eps_g) psi and a_l = H_l psi, the partial sums accumulate), ONE exchange, the correction pass to
+// H(eps_new), then the Horner rounds of every set in turn (vector from the scratch again, the phase-A products of its rows from LDS,
+// its own all-gather mailbox and counter), psi(t_n+1) back into the scratch.  The known-pulse sweeps of such a handle are batches of
+// kr_rowsplit_sweep launches (krotov_hip.hip).  A separate kernel on purpose: kr_rowsplit_sweep's code generation does not move.
+#define KR_RS_MAX_TURNS 8
+template <int NP, int NR, int LMAX>
+__global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, LMAX>::THREADS / 256)) void kr_rowsplit_turns_update(const KrSweepArgs a) {
+    using G = KrGeomR<NP, NR, LMAX>;
+    constexpr int JS = G::JS, JSR = G::JSR, JQ = G::JQ, R = G::R, NPP = G::NPP, T = G::THREADS;
+    static_assert(G::JSL == 0, "the H(eps) block in registers");
+    __shared__ __attribute__((aligned(16))) double2 sx[2][NPP];
+    __shared__ __attribute__((aligned(16))) double2 sy[2][NPP];
+    constexpr int XL = (LMAX < 2) ? 2 : LMAX;
+    __shared__ double spart[XL * NR];
+    __shared__ double stot[XL + 1];
+    __shared__ int sflag[16];
+    __shared__ double sab[KR_RS_MAX_TURNS][2 * (1 + LMAX)][NR];   // phase-A products b, a_l of the rows, per set
+    __shared__ unsigned scnt[KR_RS_MAX_TURNS];                    // all-gather counters of the sets' trajectories
+    double2 *sHl = nullptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int S = a.rs_sets;
+    const int tiles = a.P / R;   // groups
+    const int wg = a.xcd_group ? (((int)(blockIdx.x & 7) * (tiles >> 3) + (int)(blockIdx.x >> 3) / R) * R + (int)(blockIdx.x >> 3) % R) : (int)blockIdx.x;
+    const int tile = wg / R, rb = wg % R;
+    const int il = tid / JQ, jq = tid % JQ;
+    const int row = rb * NR + il;
+    const bool owner = (jq == 0), row_ok = (row < a.N);
+    const double my_rinv = kr_rinv[lane <= KR_MAX_ORDER ? lane : 0];
+    const double my_thr = kr_load_my_thr(a);
+    const KrGen<LMAX> gx = kr_gen_ctx<LMAX>(a, 0);
+    const int xoff = jq * (JS + 1);
+    const int N = a.N, NT = a.NT, L = a.L;
+    const double *econ_rows = a.econ ? a.econ + (lane & (KR_ECON_W - 1)) : nullptr;
+    const size_t slab = (size_t)a.Kp * N;
+    double2 *vscr = a.rs_scratch + (size_t)wg * KR_RS_MAX_TURNS * NP;   // this workgroup's copies of the sets' state vectors
+
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gx.Hpack, 0, (int)(a.pack_stride * 16), 0x00020000);
+    KrGroupBox box;
+    box.base = a.gmail;
+    box.tag_base = a.epoch_base2;
+    box.counter = 0;
+    box.local = false; box.tpoll = 0; box.npass = 0;
+    if (a.xcd_group) {
+        unsigned long long *xtab = a.gmail + (size_t)tiles * S * 2 * NP * 4;
+        if (tid < 64) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned ltag = a.epoch_base2 | 0x800000u;
+            if (lane == 0) __hip_atomic_store((kr_gu64 *)xtab + wg, ((unsigned long long)ltag << 32) | (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = kr_realtime();
+            bool same = false;
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load((kr_gu64 *)xtab + tile * R + (lane % R), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool got = ((unsigned)(v >> 32) == ltag);
+                if (__all(got)) { same = __all((unsigned)(v & 15u) == (xcc & 15u)); break; }
+                if (kr_realtime() - t0 > a.spin_ticks / 64) break;
+            }
+            if (lane == 0) sflag[0] = same ? 1 : 0;
+        }
+        __syncthreads();
+        box.local = (sflag[0] != 0);
+        __syncthreads();
+    }
+    if (tid < KR_RS_MAX_TURNS) scnt[tid] = 0u;
+    double gint[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) gint[l] = 0.0;
+    __syncthreads();
+
+    double Er[JSR], Ei[JSR];
+    double ecur[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) ecur[l] = 0.0;
+    // the state vector of set s at the start of step n: the initial states at n = 0, the workgroup's scratch afterwards
+    auto load_set = [&](const int s, const int n, const size_t kbase, double &pr, double &pim) {
+        const double2 *srcv = (n == 0) ? a.init + kbase : vscr + (size_t)s * NP;
+        for (int e = tid; e < NP; e += T) {
+            double2 v = make_double2(0.0, 0.0);
+            if (e < N) v = srcv[e];
+            sx[0][e + e / JS] = v;
+        }
+        pr = 0.0; pim = 0.0;
+        if (row_ok) { const double2 v = srcv[row]; pr = v.x; pim = v.y; }
+    };
+    for (int n = 0; n < NT; ++n) {
+        const double dtn = a.dt[n];
+        double e[LMAX], eg[LMAX], de[LMAX], dinc[LMAX], zero[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { eg[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0; e[l] = eg[l]; de[l] = 0.0; dinc[l] = eg[l] - ecur[l]; zero[l] = 0.0; }
+        const double ec = econ_rows ? econ_rows[(size_t)n * KR_ECON_W] : 0.0;
+        const bool refresh = (n % KR_RS_REFRESH) == 0;
+        double part[XL], du[XL];
+#pragma unroll
+        for (int l = 0; l < XL; ++l) part[l] = 0.0;
+        // ---- phase A of every set
+        for (int s = 0; s < S; ++s) {
+            const size_t kbase = ((size_t)s * tiles + tile) * N;
+            double pr, pim;
+            load_set(s, n, kbase, pr, pim);
+            double cr = 0.0, ci = 0.0;
+            if (row_ok) { const double2 c = a.X[(size_t)n * slab + kbase + row]; cr = c.x; ci = c.y; }
+            if (n == 0 && a.store && owner && row_ok) a.store[kbase + row] = make_double2(pr, pim);
+            __syncthreads();
+            double orr[1 + LMAX], oi[1 + LMAX];
+            if (s == 0) {
+                if (refresh) kr_rs_stream<NP, NR, LMAX, 1>(hrsrc, rb, L, eg, Er, Ei, sHl, &sx[0][xoff], orr, oi);
+                else kr_rs_stream<NP, NR, LMAX, 1, true>(hrsrc, rb, L, dinc, Er, Ei, sHl, &sx[0][xoff], orr, oi);
+            } else {   // the block already is H(eps_g): add nothing, take the products
+                kr_rs_stream<NP, NR, LMAX, 1, true>(hrsrc, rb, L, zero, Er, Ei, sHl, &sx[0][xoff], orr, oi);
+            }
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l)
+                if (l < L && ((gx.present >> l) & 1u)) part[l] += cr * oi[1 + l] - ci * orr[1 + l];
+            if (owner) {
+#pragma unroll
+                for (int o = 0; o <= LMAX; ++o) { sab[s][2 * o][il] = orr[o]; sab[s][2 * o + 1][il] = oi[o]; }
+            }
+            __syncthreads();   // (the next set overwrites sx[0])
+        }
+        if (!kr_exchange<XL, NR, KR_RS_SCHED>(a, n, wg, owner, il, part, du, spart, stot)) return;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < L) {
+                const double alpha = a.alpha[(size_t)l * NT + n];
+                e[l] = __dadd_rn(eg[l], __dmul_rn(alpha, du[l]));
+                de[l] = e[l] - eg[l];
+                const double ad = fabs(du[l]);
+                gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dtn));
+                if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = e[l];
+            }
+        }
+        {   // H(eps_new) = H(eps_g) + sum_l d eps_l H_l
+            double orr[1 + LMAX], oi[1 + LMAX];
+            kr_rs_stream<NP, NR, LMAX, 2>(hrsrc, rb, L, de, Er, Ei, sHl, nullptr, orr, oi);
+        }
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) ecur[l] = e[l];
+        double theta = gx.nrm[0];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) theta += fabs(e[l]) * gx.nrm[1 + l];
+        theta *= fabs(dtn);
+        int sn, m;
+        kr_plan_fast(a, my_thr, theta, sn, m);
+        int se = sn, me = m;
+        KrEcon eco = kr_econ_select(ec, theta, se, me);
+        if (eco.on && (sn > 1 || me < m)) { sn = se; m = me; }
+        else { eco.on = false; eco.a0 = 1.0; eco.a1 = 1.0; }
+        const double my_g = eco.on ? ec : my_rinv;
+        const double fs = (sn == 1) ? dtn : dtn / (double)sn;
+        // ---- Horner rounds of every set
+        for (int s = 0; s < S; ++s) {
+            const size_t traj = (size_t)s * tiles + tile;
+            const size_t kbase = traj * N;
+            box.base = a.gmail + traj * 2 * NP * 4;
+            box.counter = scnt[s];
+            double pr, pim;
+            load_set(s, n, kbase, pr, pim);
+            double orr[1 + LMAX], oi[1 + LMAX];
+#pragma unroll
+            for (int o = 0; o <= LMAX; ++o) { orr[o] = sab[s][2 * o][il]; oi[o] = sab[s][2 * o + 1][il]; }
+            __syncthreads();
+            int cur = 0;
+            for (int sub = 0; sub < sn; ++sub) {
+                const bool have_v = (sub == 0);
+                double x0r, x0i;
+                int w = 0, jlast;
+                const double2 *src;
+                if (have_v) {
+                    double wr = orr[0], wi = oi[0];
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) { wr = fma(de[l], orr[1 + l], wr); wi = fma(de[l], oi[1 + l], wi); }
+                    x0r = fs * wi; x0i = -fs * wr;
+                    if (m > 1) { if (!kr_group_gather<NP, NR, JS>(a, box, rb, owner, il, x0r, x0i, sy[0], sflag)) return; }
+                    w = 1; jlast = 2; src = sy[0];
+                } else {
+                    x0r = pr; x0i = pim; jlast = 1; src = sx[cur];
+                }
+                double yr = x0r, yi = x0i;
+                for (int j = m; j >= jlast; --j) {
+                    const bool last = (j == jlast);
+                    const bool scale0 = !have_v && last;
+                    const double f = scale0 ? fs * eco.a1 : fs * kr_rinv_lane(my_g, j);
+                    double sr, si;
+                    kr_rs_row_dot<JS, JSR, JQ, (JS >= 8 ? 8 : JS), T>(Er, Ei, sHl, src + xoff, sr, si);
+                    yr = fma(f, si, scale0 ? eco.a0 * x0r : x0r);
+                    yi = fma(-f, sr, scale0 ? eco.a0 * x0i : x0i);
+                    if (last && have_v) { yr = fma(eco.a1, yr, eco.a0 * pr); yi = fma(eco.a1, yi, eco.a0 * pim); }
+                    double2 *dst = last ? sx[cur ^ 1] : sy[w];
+                    if (!kr_group_gather<NP, NR, JS>(a, box, rb, owner, il, yr, yi, dst, sflag)) return;
+                    src = sy[w];
+                    w ^= 1;
+                }
+                if (have_v && m == 1) {
+                    yr = fma(eco.a1, x0r, eco.a0 * pr); yi = fma(eco.a1, x0i, eco.a0 * pim);
+                    if (!kr_group_gather<NP, NR, JS>(a, box, rb, owner, il, yr, yi, sx[cur ^ 1], sflag)) return;
+                }
+                pr = yr; pim = yi;
+                cur ^= 1;
+            }
+            if (a.store && owner && row_ok) a.store[(size_t)(n + 1) * slab + kbase + row] = make_double2(pr, pim);
+            for (int e = tid; e < NP; e += T) if (e < N) vscr[(size_t)s * NP + e] = sx[cur][e + e / JS];
+            if (tid == 0) scnt[s] = box.counter;
+            if (n == NT - 1 && a.fin && owner && row_ok) a.fin[kbase + row] = make_double2(pr, pim);
+            __syncthreads();   // (scratch stores are this workgroup's own: visible to its later loads; the barrier orders LDS)
+        }
+    }
+    if (wg == 0 && tid == 0) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
+    }
+}
+
 // kind: 0 known sweep, 1 update sweep; nr = rows per workgroup
 template <int NP>
 static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
@@ -505,6 +722,20 @@ static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hi
         if (kind == 0) kr_launch_kernel((kr_rowsplit_sweep<NP, NRv, LM, false>), grid, KrGeomR<NP, NRv, LM>::THREADS, 0, s, *a); \
         else kr_launch_kernel((kr_rowsplit_sweep<NP, NRv, LM, true>), grid, KrGeomR<NP, NRv, LM>::THREADS, 0, s, *a);             \
         return hipGetLastError();                                                                      \
+    }
+    if constexpr (NP >= 512) {   // kind 5: the update sweep in turns (kr_rowsplit_turns_update), one or two controls
+        if (kind == 5) {
+            if (a->rs_sets < 1 || a->rs_sets > KR_RS_MAX_TURNS || a->rs_scratch == nullptr) return hipErrorInvalidValue;
+#define KR_CASE_T(LM, NRv)                                                                             \
+            if (lmax == LM && nr == NRv) {                                                             \
+                kr_launch_kernel((kr_rowsplit_turns_update<NP, NRv, LM>), grid, KrGeomR<NP, NRv, LM>::THREADS, 0, s, *a); \
+                return hipGetLastError();                                                              \
+            }
+            KR_CASE_T(1, 8) KR_CASE_T(2, 8)
+            if constexpr (NP == 512) { KR_CASE_T(1, 16) KR_CASE_T(2, 16) }
+#undef KR_CASE_T
+            return hipErrorInvalidValue;
+        }
     }
     if constexpr (NP == 128) { KR_CASE_R(1, 128) KR_CASE_R(2, 128) }   // R = 1: one workgroup per trajectory (L <= 2: LMAX = 4 spills)
     if constexpr (NP == 1024) {  // 512 < N <= 1024: 8 rows per workgroup (128 workgroups per trajectory), one or two controls

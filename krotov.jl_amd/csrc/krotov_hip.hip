@@ -54,6 +54,8 @@ struct kr_handle {
     int rs_batch = 0;          // > 0: N > 256 with more trajectories than one row-split launch carries -- the KNOWN-pulse sweeps run the
                                // row-split kernel in batches of rs_batch trajectories (independent launches), the update sweep is the stepped
                                // generic one (its per-step sum needs every trajectory)
+    int rs_turns = 0;          // > 0 (with rs_batch): the update sweep runs kr_rowsplit_turns_update, every group of R workgroups carrying
+                               // rs_turns trajectories in turn (kr_device_rowsplit.h); 0 with rs_batch > 0: stepped generic update
     bool rs_pair = false;      // row-split PAIR mode (kr_device_rowsplit2.h): R workgroups share two trajectories and interleave them
     int R = 1, NR = 0;
     kr_launch_fn launch_rs = nullptr;
@@ -276,7 +278,7 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
 static const char *const kr_option_names[] = {
     "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
     "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "POLL_DELAY", "PRECOMP", "ROWSPLIT",
-    "RS512", "RS_BATCH", "RS_LMAX1", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
+    "RS512", "RS_BATCH", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
 static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
     out.clear();
     if (!text) return true;
@@ -585,6 +587,12 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
         if (((long long)c.K * R <= maxwg || rs_sets > 1 || rs_batch > 0) && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
             while (rs_batch == 0 && NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
             h->rs_batch = rs_batch;
+            // the update sweep of such a handle: turns inside one persistent kernel (shared generator, one or two controls, at most
+            // KR_RS_MAX_TURNS = 8 trajectories per group); otherwise the stepped generic update
+            if (rs_batch > 0 && h->G == 1 && c.L <= 2 && opt_int(h, "RS_TURNS", 1) != 0) {
+                const int turns = (c.K + rs_batch - 1) / rs_batch;
+                if (turns <= 8) h->rs_turns = turns;
+            }
             h->rowsplit = true;
             if (c.L == 1 && opt_int(h, "RS_LMAX1", 1) != 0) h->LMAXv = 1;   // row-split kernels have an instantiation for ONE control (C5): fewer
                                                                                  // accumulators and chunk registers in the streaming passes
@@ -612,6 +620,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             h->Kp = ((c.K + h->KT - 1) / h->KT) * h->KT;   // pair mode: padded to an even count
             h->P = (h->Kp / h->KT) * R;
             if (h->rs_batch > 0) h->P = std::min(c.K, h->rs_batch) * R;   // (one batch: the grid of a known-pulse launch)
+            if (h->rs_turns > 0) { h->Kp = h->rs_batch * h->rs_turns; h->P = h->rs_batch * R; }   // groups x turns, zero trajectories behind the last real one
             if (h->rs_sets > 1) {   // groups x sets pairs, zero trajectories behind the last real one
                 const int groups = maxwg / R;
                 h->Kp = 2 * groups * h->rs_sets;
@@ -783,7 +792,8 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
             if (h->NP <= 64 && !h->rowsplit) kind |= (sched ? 16 : 0) | (h->herm ? 64 : 0);
             else if (sched) break;
             q.on = 1; q.blocks_per_cu = -2;
-            if (h->rowsplit) (void)h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 3 : 1, h->P, nullptr, &dummy);
+            if (h->rowsplit && h->rs_turns > 0) { dummy.rs_sets = h->rs_turns; dummy.rs_scratch = (double2 *)16; (void)h->launch_rs(h->LMAXv, h->NR, 5, h->P, nullptr, &dummy); }
+            else if (h->rowsplit) (void)h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 3 : 1, h->P, nullptr, &dummy);
             else if (h->mfma_sweep) (void)kr_launch_mf64(h->LMAXv, (h->KT / 2) | (h->sets > 1 ? h->sets << 8 : 0), kind, h->P, nullptr, &dummy);
             else (void)h->launch(h->LMAXv, h->KT, kind, h->P, nullptr, &dummy);
             q.on = 0;
@@ -803,7 +813,7 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
     if (!h->fast_ok && genv == 0 && !poly) return rc;
     // exchange
     int ex = c.exchange;
-    const bool update_fast = h->fast_ok && h->rs_batch == 0;   // (batched row-split plan: only the known-pulse sweeps are persistent)
+    const bool update_fast = h->fast_ok && (h->rs_batch == 0 || h->rs_turns > 0);   // (batched row-split plan: only the known-pulse sweeps are persistent)
     if (ex == KR_EXCHANGE_AUTO) ex = update_fast ? KR_EXCHANGE_MAILBOX : (c.world > 1 ? KR_EXCHANGE_RCCL : KR_EXCHANGE_MAILBOX);
     if (ex == KR_EXCHANGE_MAILBOX && !update_fast && c.world > 1)
         return fail(h, KR_ERR_UNSUPPORTED, "this problem runs on the generic kernels (%s); with world > 1 they need exchange = RCCL or CALLBACK", h->err.c_str());
@@ -1161,6 +1171,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         CHK(dalloc(&h->gmail_d, h->gmail_words));
         CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
         if (h->rs_sets > 1) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * 4 /* KR_PAIR_MAX_SETS */ * 2 * NP));
+        if (h->rs_turns > 0) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * 8 /* KR_RS_MAX_TURNS */ * NP));
     }
     std::vector<double> dt(NT);
     for (int n = 0; n < NT; ++n) dt[n] = cfg->tlist[n + 1] - cfg->tlist[n];
@@ -1645,7 +1656,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
             a.econ = h->econ_d;
         }
         if (h->rs_batch > 0) {   // batches of trajectories, one launch each (known-pulse sweeps: the trajectories are independent)
-            const int N = h->cfg.N, K = h->cfg.K;
+            const int N = h->cfg.N, K = (h->rs_turns > 0) ? h->Kp : h->cfg.K;   // (turns: the zero trajectories of the padding take part)
             for (int b0 = 0; b0 < K; b0 += h->rs_batch) {
                 const int nb = std::min(h->rs_batch, K - b0);
                 if (b0 > 0) { rc = rowsplit_prelaunch(h, a); if (rc) return rc; }
@@ -1752,7 +1763,8 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     if (h->rowsplit) {
         rc = rowsplit_prelaunch(h, a);
         if (rc) return rc;
-        HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 3 : 1, h->P, h->stream, &a));
+        if (h->rs_turns > 0) a.rs_sets = h->rs_turns;
+        HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_turns > 0 ? 5 : (h->rs_pair ? 3 : 1), h->P, h->stream, &a));
     } else
     {   // update kernel variant: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (kr_launch_np); N <= 64 only
         int kind = 1;
