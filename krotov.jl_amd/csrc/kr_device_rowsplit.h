@@ -498,7 +498,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
 }
 
 // =============================================================================================
-// Update sweep IN TURNS (round 3, NP >= 512): more trajectories than groups of R workgroups -- every group carries a.rs_sets
+// Update sweep IN TURNS (round 3; NP >= 512, and NP = 256 with two controls): more trajectories than groups of R workgroups -- every group carries a.rs_sets
 // trajectories, set s = trajectory s * groups + group.  The H(eps) block is resident once and serves every set (shared generator).
 // Per step: phase A of every set in turn (its vector from the workgroup's global scratch into LDS, one streamed pass over the
 // control blocks for b = H(eps_g) psi and a_l = H_l psi, the partial sums accumulate), ONE exchange, the correction pass to
@@ -723,7 +723,7 @@ static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hi
         else kr_launch_kernel((kr_rowsplit_sweep<NP, NRv, LM, true>), grid, KrGeomR<NP, NRv, LM>::THREADS, 0, s, *a);             \
         return hipGetLastError();                                                                      \
     }
-    if constexpr (NP >= 512) {   // kind 5: the update sweep in turns (kr_rowsplit_turns_update), one or two controls
+    if constexpr (NP >= 256) {   // kind 5: the update sweep in turns (kr_rowsplit_turns_update), one or two controls
         if (kind == 5) {
             if (a->rs_sets < 1 || a->rs_sets > KR_RS_MAX_TURNS || a->rs_scratch == nullptr) return hipErrorInvalidValue;
 #define KR_CASE_T(LM, NRv)                                                                             \
@@ -731,7 +731,8 @@ static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hi
                 kr_launch_kernel((kr_rowsplit_turns_update<NP, NRv, LM>), grid, KrGeomR<NP, NRv, LM>::THREADS, 0, s, *a); \
                 return hipGetLastError();                                                              \
             }
-            KR_CASE_T(1, 8) KR_CASE_T(2, 8)
+            if constexpr (NP == 256) { KR_CASE_T(2, 32) }   // (one control at N <= 256: pair mode with sets)
+            else { KR_CASE_T(1, 8) KR_CASE_T(2, 8) }
             if constexpr (NP == 512) { KR_CASE_T(1, 16) KR_CASE_T(2, 16) }
 #undef KR_CASE_T
             return hipErrorInvalidValue;

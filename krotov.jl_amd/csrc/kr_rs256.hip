@@ -3,6 +3,7 @@
 // kind: 0 known sweep, 1 update sweep (single mode, kr_device_rowsplit.h); 2 known sweep, 3 update sweep in PAIR mode (kr_device_rowsplit2.h:
 // one control, nr <= 32)
 hipError_t kr_launch_rs256(int lmax, int nr, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
+    if (kind == 5) return kr_launch_rowsplit_np<256>(lmax, nr, kind, grid, s, a);   // update sweep in turns (single mode, two controls)
     if (kind >= 2) {
         if (lmax != 1) return hipErrorInvalidValue;
         if (a->rs_sets > 1) {   // several pairs per group in turn (N = 256, 65..256 trajectories): NR = 32 only

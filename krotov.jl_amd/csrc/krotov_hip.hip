@@ -584,6 +584,11 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
         if (NP == 128 && c.L <= 2 && (long long)c.K * R > maxwg && c.K <= maxwg && opt_int(h, "RS_R1", 1) != 0) R = 1;
         int rs_batch = 0;
         if (NP >= 512 && (long long)c.K * R > maxwg && R <= maxwg && opt_int(h, "RS_BATCH", 1) != 0) rs_batch = maxwg / R;
+        // 128 < N <= 256 with two controls and more trajectories than 4 workgroups each allow (round 3, end): groups of 8 workgroups
+        // (32 rows each: the H(eps) block in registers) with up to 8 trajectories per group in turn, known-pulse sweeps in batches --
+        // instead of the streamed-generator kernels.  (One control: pair mode with sets.  More turns: streamed kernels as before.)
+        if (NP == 256 && c.L == 2 && h->G == 1 && (long long)c.K * R > maxwg && maxwg >= 8 && (c.K + maxwg / 8 - 1) / (maxwg / 8) <= 8 &&
+            opt_int(h, "RS_BATCH", 1) != 0 && opt_int(h, "RS_TURNS", 1) != 0) { R = 8; rs_batch = maxwg / 8; }
         if (((long long)c.K * R <= maxwg || rs_sets > 1 || rs_batch > 0) && (long long)c.NT * (KR_MAX_ORDER + 2) * 4 < (1ll << 24)) {
             while (rs_batch == 0 && NP / (2 * R) >= 8 && (long long)c.K * 2 * R <= maxwg) R *= 2;
             h->rs_batch = rs_batch;

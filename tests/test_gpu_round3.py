@@ -433,7 +433,7 @@ def test_economized_polynomial_in_rowsplit_kernels(oracle_c, monkeypatch, case):
     elif case == "single_r1":              # one workgroup per trajectory, resident generator
         p, pair = wl.dense_problem(128, 36, 256, 1, 885, 0.05, 2.0), False
     elif case == "streamed":               # more trajectories than the row-split plans take: streamed-generator kernels
-        p, pair = wl.dense_problem(200, 30, 70, 2, 888, 0.05, 2.0), False
+        p, pair = wl.dense_problem(200, 30, 70, 3, 888, 0.05, 2.0), False     # (three controls: with two, turns in the row-split kernels)
     elif case == "single_two_controls":    # R = 8 workgroups per trajectory, two controls
         p, pair = wl.dense_problem(200, 36, 24, 2, 886, 0.05, 2.0), False
     elif case == "single_generators":      # per-trajectory generators, one of them not Hermitian: its steps take Taylor's plan
@@ -526,6 +526,11 @@ def test_state_dimension_above_256_with_more_trajectories(oracle_c):
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=(N == 264))
         assert info["generic_known"] == 0 and info["generic_update"] == 0 and info["K_padded"] == Kp and info["workgroups"] == 256, info
+    # 128 < N <= 256 with two controls and more than 64 trajectories: turns in groups of 8 workgroups instead of the streamed kernels
+    for (N, NT, K, L, Kp) in [(256, 36, 128, 2, 128), (200, 4, 70, 2, 96), (160, 3, 250, 2, 256)]:
+        p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
+        info = tp._run_case(oracle_c, p, check_storage=(N == 200))
+        assert info["NP"] == 256 and info["rowsplit_R"] == 8 and info["generic_update"] == 0 and info["K_padded"] == Kp, info
     for (N, NT, K, L) in [(300, 4, 70, 1), (264, 4, 9, 3)]:                        # nine turns / three controls: generic update
         p = wl.dense_problem(N, NT, K, L, 7800 + N + K, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=False)
