@@ -9,6 +9,7 @@
 #define KR_MAX_ORDER 48
 #define KR_MAIL_REPLICAS 8      // copies of the per-step mailbox, one per XCD (kr_exchange)
 #define KR_MAIL_RSTRIDE (65536 / 8)   // unsigned long longs between replicas
+#define KR_RS_MAX_TURNS 16     // update sweep in turns (kr_rowsplit_turns_update): trajectories a group of workgroups carries at most
 #define KR_ECON_W 32           // doubles per row of the economized-polynomial table: [0] a0, [1] a1, [j] a_j / a_{j-1} (2 <= j <= m <= 29), [30] theta_c, [31] m
 #ifndef KR_APPLY_JQ64
 #define KR_APPLY_JQ64 8          // lanes per row of the apply sweep at NP = 64 (8: 512-thread workgroups)

@@ -505,7 +505,6 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
 // H(eps_new), then the Horner rounds of every set in turn (vector from the scratch again, the phase-A products of its rows from LDS,
 // its own all-gather mailbox and counter), psi(t_n+1) back into the scratch.  The known-pulse sweeps of such a handle are batches of
 // kr_rowsplit_sweep launches (krotov_hip.hip).  A separate kernel on purpose: kr_rowsplit_sweep's code generation does not move.
-#define KR_RS_MAX_TURNS 8
 template <int NP, int NR, int LMAX>
 __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, LMAX>::THREADS / 256)) void kr_rowsplit_turns_update(const KrSweepArgs a) {
     using G = KrGeomR<NP, NR, LMAX>;
