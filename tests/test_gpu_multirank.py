@@ -32,6 +32,8 @@ def _problem(which):
         return wl.dense_problem(16, 60, 24, 2, 915, 0.1, 1.0), 24   # the shape of a 32-trajectory shard on each GPU of an 8-GPU run
     if which == "tile_sets":  # N = 64, 600 trajectories per rank on 64 workgroups: four tile sets per workgroup (round 3), partial sums of all
         return wl.dense_problem(64, 8, 1200, 2, 916, 0.05, 0.05), 1200   # sets accumulated in front of the one exchange that crosses the ranks
+    if which == "turns":      # N = 280 -> NP = 512: 32 workgroups per trajectory, 2 groups per rank (64 workgroups), 4 trajectories per rank in
+        return wl.dense_problem(280, 8, 8, 2, 917, 0.02, 1.0), 8        # two turns (kr_rowsplit_turns_update), known-pulse sweeps in batches
     if which == "odd_nt":     # odd N_T: consecutive launches must keep alternating the mailbox buffers
         return wl.dense_problem(16, 61, 24, 2, 911, 0.1, 1.0), 24
     return wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0), 24
@@ -59,6 +61,8 @@ def _worker(rank, world, port, q, which="small"):
         eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], b - a, device=0, rank=rank, world=world, K_global=K, max_workgroups=max_wg)
         if which == "xcd_local":
             assert "one-XCD placement 1" in eng.plan(), eng.plan()
+        if which == "turns":
+            assert "kr_rowsplit_turns_update" in eng.plan() and "sets per workgroup 2" in eng.plan(), eng.plan()
         connect_peers(eng, dist)
         eng.set_initial_states(p["psi0"][a:b])
         psiT = eng.forward(p["eps"])
@@ -117,7 +121,7 @@ def _run_ranks(which, world):
     return got
 
 
-@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks", "xcd_local", "tile_sets"])
+@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks", "xcd_local", "tile_sets", "turns"])
 def test_two_ranks_one_gpu_equals_unsharded(which):
     world = 4 if which == "four_ranks" else 2
     sys.path.insert(0, ROOT)
