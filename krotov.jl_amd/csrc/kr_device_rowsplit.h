@@ -732,6 +732,7 @@ static hipError_t kr_launch_rowsplit_np(int lmax, int nr, int kind, int grid, hi
             }
             if constexpr (NP == 256) { KR_CASE_T(2, 32) }   // (one control at N <= 256: pair mode with sets)
             else { KR_CASE_T(1, 8) KR_CASE_T(2, 8) }
+            if constexpr (NP == 512) { KR_CASE_T(4, 8) }
             if constexpr (NP == 512) { KR_CASE_T(1, 16) KR_CASE_T(2, 16) }
 #undef KR_CASE_T
             return hipErrorInvalidValue;

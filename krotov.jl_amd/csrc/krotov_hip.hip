@@ -594,7 +594,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             h->rs_batch = rs_batch;
             // the update sweep of such a handle: turns inside one persistent kernel (shared generator, one or two controls, at most
             // KR_RS_MAX_TURNS trajectories per group); otherwise the stepped generic update
-            if (rs_batch > 0 && h->G == 1 && c.L <= 2 && opt_int(h, "RS_TURNS", 1) != 0) {
+            if (rs_batch > 0 && h->G == 1 && (c.L <= 2 || NP == 512) && opt_int(h, "RS_TURNS", 1) != 0) {   // (three or four controls: NP = 512 only)
                 const int turns = (c.K + rs_batch - 1) / rs_batch;
                 if (turns <= KR_RS_MAX_TURNS) h->rs_turns = turns;
             }
@@ -1173,6 +1173,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         // memory: the XCD-local path of the all-gather lives on L2 hits
         h->gmail_words = (size_t)h->Kp * 2 * NP * 4 + (size_t)h->P;
         h->xcd_group = ((h->Kp / h->KT) % 8 == 0) && opt_int(h, "XCD_GROUP", 1) != 0;   // (tiles % 8: pairs in pair mode)
+        if (h->rs_batch > 0) h->xcd_group = h->xcd_group && (h->rs_batch % 8 == 0);   // (turns / batches: the GROUPS of a launch are the tiles)
         CHK(dalloc(&h->gmail_d, h->gmail_words));
         CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
         if (h->rs_sets > 1) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * 4 /* KR_PAIR_MAX_SETS */ * 2 * NP));

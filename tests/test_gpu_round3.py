@@ -518,11 +518,13 @@ def test_state_dimension_above_256_with_more_trajectories(oracle_c):
     """More trajectories than one NP = 512 / 1024 row-split launch carries (round 3).  The KNOWN-pulse sweeps run the row-split kernel
     in batches of trajectories (independent launches); the update sweep runs kr_rowsplit_turns_update -- every group of workgroups
     carries up to 16 trajectories in turn, H(eps) resident once, one exchange per step (N = 512, K = 32: 79 / 103 us per step against
-    ~6 / 1.5 ms on the generic kernels) -- or, beyond 16 turns, with more than two controls or per-trajectory generators, the stepped
+    ~6 / 1.5 ms on the generic kernels) -- or, beyond 16 turns or with per-trajectory generators, the stepped
     generic update.  More than four controls (two beyond N = 512): the generic kernels everywhere, as before.  Same results."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_gpu_parity as tp
-    for (N, NT, K, L, Kp) in [(300, 5, 20, 1, 24), (264, 40, 9, 2, 16), (520, 3, 3, 1, 4), (400, 4, 70, 2, 72)]:   # turns (264: across a rebuild of H(eps))
+    # turns (264: across a rebuild of H(eps); 520 with 8: a multiple of 8 trajectories on TWO groups -- the one-XCD layout of the
+    # workgroup ids goes by the groups of a launch, not by the trajectories)
+    for (N, NT, K, L, Kp) in [(300, 5, 20, 1, 24), (264, 40, 9, 2, 16), (520, 3, 3, 1, 4), (400, 4, 70, 2, 72), (520, 3, 8, 1, 8)]:
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=(N == 264))
         assert info["generic_known"] == 0 and info["generic_update"] == 0 and info["K_padded"] == Kp and info["workgroups"] == 256, info
@@ -531,7 +533,11 @@ def test_state_dimension_above_256_with_more_trajectories(oracle_c):
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=(N == 200))
         assert info["NP"] == 256 and info["rowsplit_R"] == 8 and info["generic_update"] == 0 and info["K_padded"] == Kp, info
-    for (N, NT, K, L) in [(300, 3, 130, 1), (264, 4, 9, 3)]:                       # seventeen turns / three controls: generic update
+    for (K, Kp) in [(9, 12), (16, 16)]:                                            # three controls: 8 rows per workgroup, 4 trajectories at once, 3 / 4 turns
+        p = wl.dense_problem(264, 4, K, 3, 7800 + 264 + K, 0.02, 2.0)
+        info = tp._run_case(oracle_c, p, check_storage=False)
+        assert info["generic_update"] == 0 and info["rowsplit_R"] == 64 and info["K_padded"] == Kp, info
+    for (N, NT, K, L) in [(300, 3, 130, 1)]:                                       # seventeen turns: batched known-pulse sweeps + generic update
         p = wl.dense_problem(N, NT, K, L, 7800 + N + K, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=False)
         assert info["generic_known"] == 0 and info["generic_update"] == 1 and info["rowsplit_R"] in (32, 64), info
