@@ -9,8 +9,8 @@ hipError_t kr_launch_generic(int kind, int ktg, int grid, size_t lds_bytes, hipS
             hipError_t e_ = hipSuccess;                                                                                 \
             if (kind == 0) e_ = kr_raise_dynamic_lds((const void *)kr_gen_known<KTG>, 160 * 1024);                     \
             else if (kind == 1) e_ = kr_raise_dynamic_lds((const void *)kr_gen_partial<KTG>, 160 * 1024 - 2048);       \
-            else if (kind == 4) e_ = kr_raise_dynamic_lds((const void *)kr_gen_apply<KTG>, 160 * 1024);                \
-            if (e_ != hipSuccess) return e_;                                                                            \
+            else if (kind == 4) e_ = kr_raise_dynamic_lds((const void *)kr_gen_apply<KTG>, 160 * 1024 - 4096); /* (2 KB static since the fused reduce) */ \
+            if (e_ != hipSuccess) { (void)hipGetLastError(); return e_; }                                              \
         }                                                                                                               \
         if (kind == 0) hipLaunchKernelGGL((kr_gen_known<KTG>), dim3(grid), dim3(256), lds_bytes, s, *a);                \
         else if (kind == 1) hipLaunchKernelGGL((kr_gen_partial<KTG>), dim3(grid), dim3(256), lds_bytes, s, *a);         \

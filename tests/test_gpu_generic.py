@@ -74,6 +74,17 @@ def test_beyond_the_capacity_of_the_persistent_kernels(oracle_c):
     assert info["generic_update"] == 1 and info["K_padded"] >= 8200                               #  sized them against the persistent mailbox)
 
 
+@pytest.mark.parametrize("N,K,L", [(130, 33, 1), (400, 5, 2), (129, 4, 3)])
+def test_generic_kernels_with_more_than_48_kb_of_lds(oracle_c, monkeypatch, N, K, L):
+    """Generic kernels whose dynamic LDS exceeds the 48 KB a kernel gets by default (N = 130 with four trajectories per tile: 49.7 KB;
+    N = 400 with two: 59 KB): the limit is raised per kernel and device -- and must leave room for the kernel's STATIC LDS (the
+    fused forward step of round 3 carries 2 KB of it: raising the dynamic limit to the full 160 KB failed with `invalid argument`,
+    found by tools/plan_fuzz.py at the end of round 3)."""
+    monkeypatch.setenv("KROTOV_HIP_GENERIC", "1")
+    info = _check(oracle_c, wl.dense_problem(N, 3, K, L, 330 + N, 0.03, 1.0), check_storage=False)
+    assert info["generic_known"] == 1 and info["generic_update"] == 1
+
+
 def test_generic_with_generators_and_masks(oracle_c, monkeypatch):
     monkeypatch.setenv("KROTOV_HIP_GENERIC", "1")
     import krotov_oracle as o
