@@ -22,6 +22,20 @@ for it in range(count):
     if N * K * (NT + 1) > 40e6 or (N > 512 and K > 64):
         continue
     p = wl.dense_problem(N, NT, K, L, 5000 + it, 0.03, 2.0)
+    kw = {}
+    tag = ""
+    if rng.random() < 0.25:      # a drift that is not Hermitian (weak or strong dissipation)
+        p["H0"] = p["H0"] - 1j * float(rng.choice([0.003, 0.2])) * np.diag(rng.uniform(0, 1, N))
+        tag += " nonherm"
+    if rng.random() < 0.25 and K >= 2:   # two generators, trajectories assigned at random
+        p["H0"] = np.stack([p["H0"], 0.9 * p["H0"]])
+        p["Hc"] = np.stack([p["Hc"], 1.1 * p["Hc"]])
+        kw["traj_generator"] = rng.integers(0, 2, K).astype(np.int32)
+        tag += " G=2"
+    if rng.random() < 0.25:      # a non-uniform time grid
+        dts = np.diff(p["tlist"]) * rng.uniform(0.6, 1.4, NT)
+        p["tlist"] = np.concatenate([[0.0], np.cumsum(dts)])
+        tag += " grid"
     res = {}
     t0 = time.time()
     try:
@@ -30,7 +44,7 @@ for it in range(count):
                 os.environ["KROTOV_HIP_GENERIC"] = gen
             else:
                 os.environ.pop("KROTOV_HIP_GENERIC", None)
-            with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+            with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, **kw) as eng:
                 eng.set_initial_states(p["psi0"])
                 psiT = eng.forward(p["eps"])
                 _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
@@ -42,9 +56,9 @@ for it in range(count):
         d1 = np.max(np.abs(res[""][1] - res["1"][1])) / max(np.max(np.abs(res["1"][1])), 1e-300)
         d2 = np.max(np.abs(res[""][2] - res["1"][2]))
         ok = d0 < 1e-10 and d1 < 1e-10 and d2 < 1e-10 and np.max(np.abs(res[""][1] - p["eps"])) > 0
-        print("%-4s N=%4d K=%4d L=%d NT=%2d  NP=%4d R=%3d wg=%3d Kp=%4d genK=%d genU=%d  dpsi %.1e deps %.1e dpsi1 %.1e  %.1fs" % (
+        print("%-4s N=%4d K=%4d L=%d NT=%2d  NP=%4d R=%3d wg=%3d Kp=%4d genK=%d genU=%d  dpsi %.1e deps %.1e dpsi1 %.1e  %.1fs%s" % (
             "ok" if ok else "BAD", N, K, L, NT, info["NP"], info["rowsplit_R"], info["workgroups"], info["K_padded"], info["generic_known"],
-            info["generic_update"], d0, d1, d2, time.time() - t0), flush=True)
+            info["generic_update"], d0, d1, d2, time.time() - t0, tag), flush=True)
         bad += 0 if ok else 1
     except Exception as exc:  # noqa: BLE001
         bad += 1
