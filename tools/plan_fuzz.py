@@ -1,7 +1,7 @@
 """Developer tool: cross-check of the PLANS.  Random shapes (N, K, L) around the boundaries between the kernel families run one
 Krotov iteration on the plan kr_create picks and on the generic multi-pass kernels (KROTOV_HIP_GENERIC=1, independent code);
 pulses and final states must agree to 1e-10.  Catches hangs (bounded spins -> error), layout slips and wrong plan limits.
-   python tools/plan_fuzz.py [COUNT=60] [SEED=1]"""
+   python tools/plan_fuzz.py [COUNT=60] [SEED=1]        (FUZZ_MAXWG=64,100: draw kr_config.max_workgroups from that list)"""
 import os
 import sys
 import time
@@ -24,6 +24,9 @@ for it in range(count):
     p = wl.dense_problem(N, NT, K, L, 5000 + it, 0.03, 2.0)
     kw = {}
     tag = ""
+    if os.environ.get("FUZZ_MAXWG"):     # a share of the GPU (several ranks or handles per device): the plans change with it
+        kw["max_workgroups"] = int(rng.choice([int(x) for x in os.environ["FUZZ_MAXWG"].split(",")]))
+        tag += " maxwg=%d" % kw["max_workgroups"]
     if rng.random() < 0.25:      # a drift that is not Hermitian (weak or strong dissipation)
         p["H0"] = p["H0"] - 1j * float(rng.choice([0.003, 0.2])) * np.diag(rng.uniform(0, 1, N))
         tag += " nonherm"
