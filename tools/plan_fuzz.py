@@ -1,7 +1,8 @@
 """Developer tool: cross-check of the PLANS.  Random shapes (N, K, L) around the boundaries between the kernel families run one
 Krotov iteration on the plan kr_create picks and on the generic multi-pass kernels (KROTOV_HIP_GENERIC=1, independent code);
 pulses and final states must agree to 1e-10.  Catches hangs (bounded spins -> error), layout slips and wrong plan limits.
-   python tools/plan_fuzz.py [COUNT=60] [SEED=1]        (FUZZ_MAXWG=64,100: draw kr_config.max_workgroups from that list)"""
+   python tools/plan_fuzz.py [COUNT=60] [SEED=1]        (FUZZ_MAXWG=64,100: draw kr_config.max_workgroups from that list;
+    FUZZ_NMAX=64: small state dimensions with up to 4200 trajectories)"""
 import os
 import sys
 import time
@@ -16,6 +17,9 @@ count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 NS = [9, 16, 33, 64, 65, 100, 128, 130, 200, 256, 257, 300, 400, 512, 513, 700, 1024]
 KS = [1, 2, 3, 5, 8, 9, 16, 17, 31, 32, 33, 64, 65, 100, 128, 130, 250, 256, 257, 300, 520]
+if os.environ.get("FUZZ_NMAX"):          # e.g. FUZZ_NMAX=64: the register-resident / matrix-core kernels with many trajectories
+    NS = [n for n in NS if n <= int(os.environ["FUZZ_NMAX"])] + [8, 12, 20, 32, 48, 64]
+    KS = KS + [600, 1024, 1100, 2048, 2100, 4096, 4200]
 bad = 0
 for it in range(count):
     N = int(rng.choice(NS)); K = int(rng.choice(KS)); L = int(rng.choice([1, 1, 2, 2, 3, 4])); NT = int(rng.choice([3, 4, 34]))
