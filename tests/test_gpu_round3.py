@@ -566,3 +566,35 @@ def test_state_dimension_up_to_1024_on_the_rowsplit_kernels(N, NT, K, L):
         assert np.max(np.abs(psiT - psiT_o)) < TOL_STATE
         eps_new, ga, psiT1 = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
     assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < TOL_GA and np.max(np.abs(psiT1 - psi1_o)) < TOL_STATE
+
+
+@pytest.mark.parametrize("N,NT,K,L,fname,fid", [(300, 6, 20, 1, "ss", 1), (264, 5, 9, 2, "sm", 0), (256, 5, 128, 2, "re", 2), (520, 4, 3, 1, "sm", 0)])
+def test_device_functional_chain_on_turns_plans(N, NT, K, L, fname, fid):
+    """kr_iteration_functional_dev (tau, chi(T) on the device) on handles whose update sweep runs in turns and whose known-pulse
+    sweeps run in batches (zero trajectories pad the last turn: they must not enter tau, J_T or the sums): two chained iterations,
+    bitwise equal to the chain with chi(T) formed on the host."""
+    import torch
+    p = wl.dense_problem(N, NT, K, L, 6100 + N, 0.03, 2.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        assert "kr_rowsplit_turns_update" in eng.plan(), eng.plan()
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        eps = p["eps"].copy()
+        for _ in range(2):
+            _, _, chiT = wl.chi_and_JT(fname, psiT, p["tgt"])
+            eps, ga, psiT = eng.iteration(eps, chiT, p["S"], p["lam"])
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        eng.set_initial_states(p["psi0"])
+        eng.set_target_states(p["tgt"])
+        eng.set_update_params(p["S"], p["lam"])
+        e0 = torch.from_numpy(p["eps"].copy()).cuda()
+        e1 = torch.empty_like(e0)
+        torch.cuda.synchronize()
+        eng.forward_dev(e0.data_ptr())
+        for _ in range(2):
+            eng.iteration_functional_dev(fid, e0.data_ptr(), e1.data_ptr())
+            e0, e1 = e1, e0
+        eng.synchronize()
+        eps_dev, psiT_dev = e0.cpu().numpy(), eng.final_states()
+    assert np.max(np.abs(eps - p["eps"])) > 1e-7
+    assert _rel(eps_dev, eps) < 1e-12 and np.max(np.abs(psiT_dev - psiT)) < 1e-12
