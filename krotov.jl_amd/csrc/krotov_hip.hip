@@ -1172,8 +1172,9 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         // vector mailboxes [K][2][NP][4] + one word per workgroup (XCD ids, see kr_rowsplit_sweep); ordinary cached
         // memory: the XCD-local path of the all-gather lives on L2 hits
         h->gmail_words = (size_t)h->Kp * 2 * NP * 4 + (size_t)h->P;
-        h->xcd_group = ((h->Kp / h->KT) % 8 == 0) && opt_int(h, "XCD_GROUP", 1) != 0;   // (tiles % 8: pairs in pair mode)
-        if (h->rs_batch > 0) h->xcd_group = h->xcd_group && (h->rs_batch % 8 == 0);   // (turns / batches: the GROUPS of a launch are the tiles)
+        // (the kernels lay the workgroup ids out by their TILES = groups of R workgroups of a launch: trajectories, pairs in pair mode,
+        //  groups with sets or turns -- not by the trajectory count, which differs from it with sets / turns / batches)
+        h->xcd_group = ((h->P / h->R) % 8 == 0) && opt_int(h, "XCD_GROUP", 1) != 0;
         CHK(dalloc(&h->gmail_d, h->gmail_words));
         CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
         if (h->rs_sets > 1) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * 4 /* KR_PAIR_MAX_SETS */ * 2 * NP));
