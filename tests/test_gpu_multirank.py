@@ -34,6 +34,10 @@ def _problem(which):
         return wl.dense_problem(64, 8, 1200, 2, 916, 0.05, 0.05), 1200   # sets accumulated in front of the one exchange that crosses the ranks
     if which == "turns":      # N = 280 -> NP = 512: 32 workgroups per trajectory, 2 groups per rank (64 workgroups), 4 trajectories per rank in
         return wl.dense_problem(280, 8, 8, 2, 917, 0.02, 1.0), 8        # two turns (kr_rowsplit_turns_update), known-pulse sweeps in batches
+    if which == "pair_sets":  # N = 256, one control, 40 trajectories per rank on 8 groups of 8 workgroups: pair mode with 3 sets per group
+        return wl.dense_problem(256, 6, 80, 1, 918, 0.02, 1.0), 80
+    if which == "turns256":   # N = 200, two controls, 40 trajectories per rank: 8 groups of 8 workgroups, 5 turns each
+        return wl.dense_problem(200, 6, 80, 2, 919, 0.02, 1.0), 80
     if which == "odd_nt":     # odd N_T: consecutive launches must keep alternating the mailbox buffers
         return wl.dense_problem(16, 61, 24, 2, 911, 0.1, 1.0), 24
     return wl.dense_problem(16, 60, 24, 2, 909, 0.1, 1.0), 24
@@ -63,6 +67,10 @@ def _worker(rank, world, port, q, which="small"):
             assert "one-XCD placement 1" in eng.plan(), eng.plan()
         if which == "turns":
             assert "kr_rowsplit_turns_update" in eng.plan() and "sets per workgroup 2" in eng.plan(), eng.plan()
+        if which == "turns256":
+            assert "kr_rowsplit_turns_update" in eng.plan() and "sets per workgroup 5" in eng.plan(), eng.plan()
+        if which == "pair_sets":
+            assert "kr_rowsplit_pair_sweep" in eng.plan() and "64 workgroups" in eng.plan(), eng.plan()
         connect_peers(eng, dist)
         eng.set_initial_states(p["psi0"][a:b])
         psiT = eng.forward(p["eps"])
@@ -121,7 +129,7 @@ def _run_ranks(which, world):
     return got
 
 
-@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks", "xcd_local", "tile_sets", "turns"])
+@pytest.mark.parametrize("which", ["small", "odd_nt", "rowsplit", "wide", "skewed", "four_ranks", "xcd_local", "tile_sets", "turns", "pair_sets", "turns256"])
 def test_two_ranks_one_gpu_equals_unsharded(which):
     world = 4 if which == "four_ranks" else 2
     sys.path.insert(0, ROOT)
