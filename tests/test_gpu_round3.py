@@ -498,7 +498,7 @@ def test_options_travel_in_kr_config(monkeypatch):
         assert "options" in str(ei.value) and bad in str(ei.value)
 
 
-@pytest.mark.parametrize("N,NT,K,L,R", [(300, 6, 3, 1, 64), (400, 5, 8, 2, 32), (512, 5, 2, 1, 64), (260, 40, 4, 2, 64), (280, 5, 3, 4, 64)])
+@pytest.mark.parametrize("N,NT,K,L,R", [(300, 6, 3, 1, 64), (400, 4, 8, 2, 32), (512, 3, 2, 1, 64), (260, 34, 4, 2, 64), (280, 4, 3, 4, 64)])
 def test_state_dimension_up_to_512_on_the_rowsplit_kernels(oracle_c, N, NT, K, L, R):
     """256 < N <= 512 (round 3): the single-mode row-split kernels with NP = 512 -- 64 or 32 workgroups per trajectory, 8 or 16 rows
     each, the all-gather polled by two waves -- instead of the generic multi-pass kernels (N = 512, K = 4: 14.6 / 19 us per step
@@ -524,7 +524,7 @@ def test_state_dimension_above_256_with_more_trajectories(oracle_c):
     import test_gpu_parity as tp
     # turns (264: across a rebuild of H(eps); 520 with 8: a multiple of 8 trajectories on TWO groups -- the one-XCD layout of the
     # workgroup ids goes by the groups of a launch, not by the trajectories)
-    for (N, NT, K, L, Kp) in [(300, 5, 20, 1, 24), (264, 40, 9, 2, 16), (520, 3, 3, 1, 4), (400, 4, 70, 2, 72), (520, 3, 8, 1, 8)]:
+    for (N, NT, K, L, Kp) in [(300, 4, 20, 1, 24), (264, 34, 9, 2, 16), (520, 2, 3, 1, 4), (400, 3, 70, 2, 72), (516, 2, 8, 1, 8)]:
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=(N == 264))
         assert info["generic_known"] == 0 and info["generic_update"] == 0 and info["K_padded"] == Kp and info["workgroups"] == 256, info
@@ -537,11 +537,11 @@ def test_state_dimension_above_256_with_more_trajectories(oracle_c):
         p = wl.dense_problem(264, 4, K, 3, 7800 + 264 + K, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=False)
         assert info["generic_update"] == 0 and info["rowsplit_R"] == 64 and info["K_padded"] == Kp, info
-    for (N, NT, K, L) in [(300, 3, 130, 1)]:                                       # seventeen turns: batched known-pulse sweeps + generic update
+    for (N, NT, K, L) in [(300, 2, 130, 1)]:                                       # seventeen turns: batched known-pulse sweeps + generic update
         p = wl.dense_problem(N, NT, K, L, 7800 + N + K, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=False)
         assert info["generic_known"] == 0 and info["generic_update"] == 1 and info["rowsplit_R"] in (32, 64), info
-    for (N, NT, K, L) in [(258, 4, 3, 5), (600, 3, 1, 3)]:
+    for (N, NT, K, L) in [(258, 3, 3, 5), (520, 2, 1, 3)]:
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=False)
         assert info["generic_known"] == 1 and info["generic_update"] == 1, info
