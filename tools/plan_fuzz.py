@@ -39,6 +39,16 @@ for it in range(count):
         p["Hc"] = np.stack([p["Hc"], 1.1 * p["Hc"]])
         kw["traj_generator"] = rng.integers(0, 2, K).astype(np.int32)
         tag += " G=2"
+    if os.environ.get("FUZZ_EXTRA"):     # FUZZ_EXTRA=1: also masks (control_derivs === nothing for one control) and a looser tolerance
+        if L >= 2 and rng.random() < 0.4:
+            G_ = p["H0"].shape[0] if p["H0"].ndim == 3 else 1
+            pres = np.ones((G_, L), np.uint8)
+            pres[int(rng.integers(0, G_)), int(rng.integers(0, L))] = 0
+            kw["hc_present"] = pres
+            tag += " mask"
+        if rng.random() < 0.3:
+            kw["prop_tol"] = 1e-11
+            tag += " tol"
     if rng.random() < 0.25:      # a non-uniform time grid
         dts = np.diff(p["tlist"]) * rng.uniform(0.6, 1.4, NT)
         p["tlist"] = np.concatenate([[0.0], np.cumsum(dts)])
@@ -62,7 +72,8 @@ for it in range(count):
         d0 = np.max(np.abs(res[""][0] - res["1"][0]))
         d1 = np.max(np.abs(res[""][1] - res["1"][1])) / max(np.max(np.abs(res["1"][1])), 1e-300)
         d2 = np.max(np.abs(res[""][2] - res["1"][2]))
-        ok = d0 < 1e-10 and d1 < 1e-10 and d2 < 1e-10 and np.max(np.abs(res[""][1] - p["eps"])) > 0
+        lim = 1e-10 if "prop_tol" not in kw else 1e-8   # (a looser truncation bound: the two plans' polynomials differ by up to it per step)
+        ok = d0 < lim and d1 < lim and d2 < lim and np.max(np.abs(res[""][1] - p["eps"])) > 0
         print("%-4s N=%4d K=%4d L=%d NT=%2d  NP=%4d R=%3d wg=%3d Kp=%4d genK=%d genU=%d  dpsi %.1e deps %.1e dpsi1 %.1e  %.1fs%s" % (
             "ok" if ok else "BAD", N, K, L, NT, info["NP"], info["rowsplit_R"], info["workgroups"], info["K_padded"], info["generic_known"],
             info["generic_update"], d0, d1, d2, time.time() - t0, tag), flush=True)
