@@ -44,7 +44,9 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 2   /* v2: kr_config grew (exchange, prop_method, device list, max_workgroups) */
+#define KR_ABI_VERSION 3   /* v2: kr_config grew (exchange, prop_method, device list, max_workgroups); v3: two of v2's reserved words became
+                            * spin_timeout_ms and the `options` pointer, which kr_create dereferences -- a v2 caller that never zeroed
+                            * `reserved` must not reach that code, so v2 configs are refused (kr_create: KR_ERR_INVALID) */
 
 enum kr_status {
     KR_OK = 0,
@@ -124,15 +126,14 @@ typedef struct kr_config {
     /* Bound of every in-kernel spin (per-step exchange between workgroups / GPUs, row-split all-gather, cross-rank tau sum)
      * in milliseconds; 0 = the default 4000.  With one process per GPU the ranks run unsynchronised between iterations, so
      * a rank whose host-side chi / callback takes longer than this bound makes the OTHER ranks' sweeps give up with
-     * KR_ERR_TIMEOUT: size it to the slowest host step.  (Occupies the first of the formerly reserved words: a v2 caller
-     * that zeroed `reserved` gets the default.)                                                                          */
+     * KR_ERR_TIMEOUT: size it to the slowest host step.  (ABI v3; the first of v2's reserved words.)                       */
     int32_t spin_timeout_ms;
     int32_t reserved0;
     /* Schedule and diagnostics options, "NAME=integer;NAME=integer" (separators ; , or white space), or NULL.  The names are those
      * INTEGRATION.md lists as KROTOV_HIP_<NAME> (the prefix is optional here); an option given here takes precedence over the
      * environment variable of the same name, which stays the fallback for the lab.  kr_create fails with KR_ERR_INVALID on a name
-     * it does not know or a value that is not an integer.  The string is parsed inside kr_create and not kept.  (Occupies formerly
-     * reserved words: a caller that zeroed `reserved` passes NULL.)                                                             */
+     * it does not know or a value that is not an integer.  The string is parsed inside kr_create and not kept.  (ABI v3; occupies
+     * words that v2 called reserved, hence the version bump: kr_create refuses a v2 config instead of reading a wild pointer.)      */
     const char *options;
     int32_t reserved[4];
 } kr_config;
@@ -204,6 +205,11 @@ int kr_debug_stamps(kr_handle *h, unsigned long long *out);
 /* Diagnostic builds of the library only (-DKR_ARRIVALS): per workgroup {publish, end of window work, completion, poll passes}
  * of two exchanges in the middle of the last update sweep, 100 MHz ticks; zeros otherwise.  words <= 8192. */
 int kr_debug_arrivals(kr_handle *h, unsigned long long *out, int words);
+/* The bounds of the operators' spectral norms that set the degree of every step polynomial (Taylor remainder, interval of the
+ * economized polynomial): out[g][0] >= ||H0_g||_2, out[g][1 + l] >= ||H_l,g||_2, [G][1 + L] doubles.  Rigorous upper bounds, at
+ * most 0.3 % above the norms (kr_norm.hip).  A handle with a device list answers for its first shard (all shards hold the same
+ * operators).                                                                                                               */
+int kr_get_norm_bounds(kr_handle *h, double *out /* [G][1 + L] */);
 
 /* Per-step exchange through RCCL (KR_EXCHANGE_RCCL): rank 0 makes a unique id, the host side broadcasts it, every
  * rank calls kr_rccl_init (collective).  librccl is loaded at run time (dlopen): no link-time dependency.

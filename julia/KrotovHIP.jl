@@ -46,7 +46,7 @@ using QuantumControl.QuantumPropagators.Controls: get_controls, evaluate
 using QuantumControl.QuantumPropagators.Interfaces: supports_inplace
 
 const LIB = get(ENV, "KROTOV_HIP_LIB", joinpath(@__DIR__, "..", "krotov.jl_amd", "lib", "libkrotov_hip.so"))
-const KR_ABI_VERSION = Int32(2)
+const KR_ABI_VERSION = Int32(3)
 
 # struct kr_config (include/krotov_hip.h, ABI v2) -- field for field
 struct KrConfig

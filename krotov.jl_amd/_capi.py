@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KROTOV_HIP_LIB", os.path.join(_HERE, "lib", "libkrotov_hip.so"))  # env: A/B builds
 
-KR_ABI_VERSION = 2
+KR_ABI_VERSION = 3
 KR_OK, KR_ERR_INVALID, KR_ERR_NO_DEVICE, KR_ERR_HIP, KR_ERR_UNSUPPORTED, KR_ERR_TIMEOUT, KR_ERR_STATE, KR_ERR_INTERNAL = range(8)
 KR_STORE_FW, KR_NO_STORE_FW = 1, 2
 KR_J_T_SM, KR_J_T_SS, KR_J_T_RE = 0, 1, 2
@@ -23,7 +23,7 @@ EXPORTS = [
     "kr_set_initial_states", "kr_set_target_states", "kr_forward", "kr_backward",
     "kr_update_forward", "kr_iteration", "kr_set_update_params", "kr_forward_dev",
     "kr_iteration_functional_dev", "kr_final_states", "kr_taus", "kr_g_a_int", "kr_synchronize",
-    "kr_read_storage", "kr_get_info", "kr_plan_description", "kr_get_timings", "kr_enable_timing", "kr_debug_stamps", "kr_debug_arrivals",
+    "kr_read_storage", "kr_get_info", "kr_plan_description", "kr_get_timings", "kr_enable_timing", "kr_debug_stamps", "kr_debug_arrivals", "kr_get_norm_bounds",
     "kr_ipc_handle_size", "kr_ipc_export", "kr_ipc_connect",
     "kr_rccl_unique_id_size", "kr_rccl_get_unique_id", "kr_rccl_init", "kr_set_exchange_callback",
 ]

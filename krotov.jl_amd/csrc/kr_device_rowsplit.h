@@ -98,7 +98,12 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
     // from memory with its first poll pass (1.2-1.9 us against 0.75 us for a pass of loads alone).
     if (owner) {
         const int e = rb * NR + il;
+#ifdef KR_GATHER_SEQ   // diagnostic build (tools/build_diag.sh): bits 15..1 of every double carry the gather counter, see below
+        const unsigned long long sq = (unsigned long long)((box.counter & 0x7fffu) << 1);
+        dst[e + e / JS] = make_double2(__longlong_as_double((long long)((kr_slot_bits(vr, phase) & ~0xfffeull) | sq)), __longlong_as_double((long long)((kr_slot_bits(vi, phase) & ~0xfffeull) | sq)));
+#else
         dst[e + e / JS] = make_double2(__longlong_as_double((long long)kr_slot_bits(vr, phase)), __longlong_as_double((long long)kr_slot_bits(vi, phase)));
+#endif
     }
     __syncthreads();
     if constexpr (NR == NP) { (void)sflag; (void)mb; return true; }   // R = 1: the workgroup owns every row
@@ -161,6 +166,22 @@ __device__ __forceinline__ bool kr_group_gather(const KrSweepArgs &a, KrGroupBox
             }
         }
         if (a.debug) { box.tpoll += __builtin_amdgcn_s_memtime() - tm0; box.npass += spins + 1; }
+#ifdef KR_GATHER_SEQ
+        // Did the one-bit validity accept an element of an EARLIER use of this buffer?  (Every element carries its gather counter in
+        // this build; a.debug[4] counts the elements whose counter is not this gather's, a.debug[8..11] keep the last such event.)
+        if (alive && a.debug) {
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                if (pwin * 256 + lane + 64 * c < NP - NR) {
+                    const unsigned want = box.counter & 0x7fffu, sr = (g[c].x >> 1) & 0x7fffu, si = (g[c].z >> 1) & 0x7fffu;
+                    if (sr != want || si != want) {
+                        atomicAdd(a.debug + 4, 1ull);
+                        a.debug[8] = (unsigned long long)blockIdx.x; a.debug[9] = box.counter; a.debug[10] = (unsigned long long)el[c]; a.debug[11] = ((unsigned long long)sr << 32) | si;
+                    }
+                }
+            }
+        }
+#endif
         if (alive) {
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
@@ -704,7 +725,13 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
             for (int e = tid; e < NP; e += T) if (e < N) vscr[(size_t)s * NP + e] = sx[cur][e + e / JS];
             if (tid == 0) scnt[s] = box.counter;
             if (n == NT - 1 && a.fin && owner && row_ok) a.fin[kbase + row] = make_double2(pr, pim);
-            __syncthreads();   // (scratch stores are this workgroup's own: visible to its later loads; the barrier orders LDS)
+            // The scratch vector is written by all threads here and read back by OTHER threads of the same workgroup in load_set
+            // (twice per step).  Workgroup-scope release / acquire around the barrier, written out: the waves of a workgroup share
+            // one CU and its vector L1 (no threadgroup-split mode), so a workgroup-scope fence is what this hand-over needs --
+            // unlike the cross-workgroup mailboxes, which go through sc0 / sc1 accesses.
+            __threadfence_block();
+            __syncthreads();
+            __threadfence_block();
         }
     }
     if (wg == 0 && tid == 0) {

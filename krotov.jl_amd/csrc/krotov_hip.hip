@@ -116,6 +116,7 @@ struct kr_handle {
     size_t gen_lds = 0, col_stride = 0;
     double2 *Hcol_fw = nullptr, *Hcol_bw = nullptr, *Heps_d = nullptr;
     int *tile_gen_d = nullptr;
+    std::vector<double> nrm_host;   // [G][1 + L] bounds of the operators' 2-norms (kr_get_norm_bounds)
     double *nrm_gen_d = nullptr, *partial_d = nullptr, *du_local_d = nullptr, *du_total_d = nullptr;
     double *du_host = nullptr;   // pinned, callback exchange
     int exchange = KR_EXCHANGE_AUTO;   // resolved at kr_create
@@ -194,53 +195,11 @@ hipError_t kr_raise_dynamic_lds(const void *func, int bytes) {
     } while (0)
 
 // ---- small host linear algebra ---------------------------------------------------------------
-// Upper bound (to a few %) of the spectral norm of a dense column-major matrix: power iteration on
-// A^H A with a safety factor, capped by sqrt(||A||_1 ||A||_inf) which is a rigorous bound.
-static double norm2_bound(int n, const zc *A) {
-    double n1 = 0, ninf = 0;
-    std::vector<double> rows(n, 0.0);
-    for (int j = 0; j < n; ++j) {
-        double s = 0;
-        for (int i = 0; i < n; ++i) { double v = std::abs(A[i + (size_t)j * n]); s += v; rows[i] += v; }
-        n1 = std::max(n1, s);
-    }
-    for (int i = 0; i < n; ++i) ninf = std::max(ninf, rows[i]);
-    const double cap = std::sqrt(n1 * ninf);
-    if (cap == 0.0) return 0.0;
-    std::vector<zc> x(n), y(n), z(n);
-    for (int i = 0; i < n; ++i) x[i] = zc(1.0 + 0.37 * std::sin(1.7 * i + 0.3), 0.21 * std::cos(2.3 * i));
-    double sigma = 0;
-    bool converged = false;
-    // (n > 256: 400 iterations -- each is two products with an n x n matrix on the host, 2000 of them cost seconds at n = 1024;
-    //  an estimate that has not settled by then takes the 5 % margin below, the Rayleigh quotient's error after k iterations
-    //  falls like (sigma_2 / sigma_1)^(4k))
-    const int max_it = (n > 256) ? 400 : 2000;
-    for (int it = 0; it < max_it; ++it) {
-        double nx = 0;
-        for (int i = 0; i < n; ++i) nx += std::norm(x[i]);
-        nx = std::sqrt(nx);
-        if (nx == 0) break;
-        for (int i = 0; i < n; ++i) x[i] /= nx;
-        for (int i = 0; i < n; ++i) y[i] = 0;
-        for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) y[i] += A[i + (size_t)j * n] * x[j];
-        double ny = 0;
-        for (int i = 0; i < n; ++i) ny += std::norm(y[i]);
-        const double s_new = std::sqrt(ny);
-        for (int j = 0; j < n; ++j) {
-            zc acc = 0;
-            for (int i = 0; i < n; ++i) acc += std::conj(A[i + (size_t)j * n]) * y[i];
-            z[j] = acc;
-        }
-        x = z;
-        converged = (it > 20 && std::fabs(s_new - sigma) <= 1e-9 * s_new);
-        sigma = s_new;
-        if (converged) break;
-    }
-    // power iteration approaches sigma_max from below: a small margin when it has converged, a larger one
-    // otherwise; never above the rigorous bound.  (The Taylor remainder bound moves by (1+d)^m for a relative
-    // error d of the norm, so the margin only has to cover the residual of the iteration.)
-    return std::min(cap, sigma * (converged ? 1.001 : 1.05));
-}
+// Spectral norms of the operators: rigorous UPPER bounds (kr_norm.hip: ||A||_2 <= ||(A^H A)^p||_F^(1/(2p)) by repeated squaring on
+// the device, at most 0.3 % above the norm).  Until round 4 a host power iteration ESTIMATED them from below (+0.1 % when its
+// convergence test fired -- it can fire on a plateau --, +5 % at its iteration cap); the Taylor remainder forgives an
+// underestimate (a factor (1 + d)^m), the economized step polynomial does not: it is accurate on [-theta_c, theta_c] only.
+hipError_t kr_norm2_upper_bounds(int n, int count, const zc *const *mats, double *bounds);
 
 // Pack generator m (column-major N x N) into the thread-major slice layout of the kernels:
 // pack[(jj)*RT + i*JQ + jq] = M[i][jq*JS + jj]  (zero outside N).  adj: use M^dagger.
@@ -921,8 +880,10 @@ static int check_status(kr_handle *h);
 static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&live) {
     if (out) *out = nullptr;
     if (!cfg || !out) return fail(nullptr, KR_ERR_INVALID, "kr_create: null argument");
-    if (cfg->spin_timeout_ms < 0) return fail(nullptr, KR_ERR_INVALID, "kr_create: spin_timeout_ms = %d must be >= 0 (0 = default 4000)", cfg->spin_timeout_ms);
+    // the version FIRST: v3 gave words a meaning that v2 called reserved (spin_timeout_ms, the options pointer) -- nothing below may
+    // look at a config of another version
     if (cfg->abi_version != KR_ABI_VERSION) return fail(nullptr, KR_ERR_INVALID, "kr_create: abi_version %d != %d", cfg->abi_version, KR_ABI_VERSION);
+    if (cfg->spin_timeout_ms < 0) return fail(nullptr, KR_ERR_INVALID, "kr_create: spin_timeout_ms = %d must be >= 0 (0 = default 4000)", cfg->spin_timeout_ms);
     if (cfg->L <= 0) return fail(nullptr, KR_ERR_INVALID, "no controls in trajectories: cannot optimize");  // workspace.jl:72
     if (cfg->N <= 0 || cfg->NT <= 0 || cfg->K <= 0) return fail(nullptr, KR_ERR_INVALID, "kr_create: N, NT, K must be positive (got %d, %d, %d)", cfg->N, cfg->NT, cfg->K);
     if (!cfg->tlist || !cfg->H0 || !cfg->Hc) return fail(nullptr, KR_ERR_INVALID, "kr_create: tlist, H0, Hc are required");
@@ -1014,12 +975,18 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         CHK(dalloc(&h->Hpack_fw, pack_elems));
         CHK(dalloc(&h->Hpack_bw, pack_elems));
     }
-    for (int g = 0; g < G; ++g) {
-        nrm_gen[(size_t)g * (1 + L)] = norm2_bound(N, H0 + (size_t)g * nn);
-        for (int l = 0; l < L; ++l) {
-            if (!cfg->hc_present || cfg->hc_present[(size_t)g * L + l]) present[g] |= 1u << l;
-            nrm_gen[(size_t)g * (1 + L) + 1 + l] = norm2_bound(N, Hc + ((size_t)g * L + l) * nn);
+    {
+        std::vector<const zc *> mats((size_t)G * (1 + L));
+        for (int g = 0; g < G; ++g) {
+            mats[(size_t)g * (1 + L)] = H0 + (size_t)g * nn;
+            for (int l = 0; l < L; ++l) mats[(size_t)g * (1 + L) + 1 + l] = Hc + ((size_t)g * L + l) * nn;
         }
+        CHK(kr_norm2_upper_bounds(N, (int)mats.size(), mats.data(), nrm_gen.data()));
+        h->nrm_host = nrm_gen;
+    }
+    for (int g = 0; g < G; ++g) {
+        for (int l = 0; l < L; ++l)
+            if (!cfg->hc_present || cfg->hc_present[(size_t)g * L + l]) present[g] |= 1u << l;
         for (int m = 0; m <= L && m <= KR_LMAX_CAP; ++m) nrm[(size_t)g * (1 + KR_LMAX_CAP) + m] = nrm_gen[(size_t)g * (1 + L) + m];
     }
     // Economized step polynomial (KrEcon, kr_device.h): needs a real spectrum, i.e. EVERY operator of every generator exactly
@@ -1041,7 +1008,11 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
                         Ms[(size_t)c * N + r] = 0.5 * (M[(size_t)c * N + r] - std::conj(M[(size_t)r * N + c]));
                         if (Ms[(size_t)c * N + r] != zc(0.0, 0.0)) herm = false;
                     }
-                if (!herm) { skw[(size_t)g * (1 + KR_LMAX_CAP) + m] = norm2_bound(N, Ms.data()); any = true; }
+                if (!herm) {
+                    const zc *mp = Ms.data();
+                    CHK(kr_norm2_upper_bounds(N, 1, &mp, &skw[(size_t)g * (1 + KR_LMAX_CAP) + m]));
+                    any = true;
+                }
             }
         if (any) {
             CHK(dalloc(&h->skw_d, skw.size()));
@@ -2334,6 +2305,13 @@ extern "C" int kr_enable_timing(kr_handle *h, int on) {
 extern "C" int kr_get_timings(kr_handle *h, double *t) { KR_ENTRY(h, "kr_get_timings", return one_get_timings(is_group(h) ? h->subs[0] : h, t);); }
 extern "C" int kr_get_info(kr_handle *h, int32_t *info) { KR_ENTRY(h, "kr_get_info", return one_get_info(is_group(h) ? h->subs[0] : h, info);); }
 extern "C" int kr_debug_stamps(kr_handle *h, unsigned long long *o) { KR_ENTRY(h, "kr_debug_stamps", return one_debug_stamps(is_group(h) ? h->subs[0] : h, o);); }
+static int one_get_norm_bounds(kr_handle *h, double *out) {
+    if (!h || !out) return h ? fail(h, KR_ERR_INVALID, "kr_get_norm_bounds: null") : KR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mtx);
+    std::copy(h->nrm_host.begin(), h->nrm_host.end(), out);
+    return KR_OK;
+}
+extern "C" int kr_get_norm_bounds(kr_handle *h, double *out) { KR_ENTRY(h, "kr_get_norm_bounds", return one_get_norm_bounds(is_group(h) ? h->subs[0] : h, out);); }
 extern "C" int kr_debug_arrivals(kr_handle *h, unsigned long long *o, int words) { KR_ENTRY(h, "kr_debug_arrivals", return one_debug_arrivals(is_group(h) ? h->subs[0] : h, o, words);); }
 extern "C" const char *kr_plan_description(const kr_handle *h) {
     if (!h) return "";

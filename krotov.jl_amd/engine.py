@@ -231,6 +231,12 @@ class HipEngine:
         self._chk(self._lib.kr_debug_arrivals(self._h, a, 8 * workgroups))
         return np.array(a, dtype=np.uint64).reshape(workgroups, 2, 4)
 
+    def norm_bounds(self):
+        """kr_get_norm_bounds: (G, 1 + L) rigorous upper bounds of ||H0||_2, ||H_l||_2 (they set the degree of every step polynomial)."""
+        out = np.empty((self.G, 1 + self.L))
+        self._chk(self._lib.kr_get_norm_bounds(self._h, capi.ptr(out)))
+        return out
+
     def plan(self):
         """kr_plan_description: one line naming the kernels, grid and exchange of this handle (and why, if not the persistent ones)."""
         msg = self._lib.kr_plan_description(self._h)

@@ -36,11 +36,24 @@ def test_header_and_binding_agree(lib):
 
 
 def test_abi_version(lib):
-    assert lib.kr_abi_version() == capi.KR_ABI_VERSION
+    assert lib.kr_abi_version() == capi.KR_ABI_VERSION == 3
+
+
+def test_a_v2_config_is_refused(lib):
+    """ABI v3 gave two of v2's `reserved` words a meaning (spin_timeout_ms, the `options` pointer that kr_create dereferences): a v2
+    caller that never zeroed them must be stopped by the version check, before anything reads those words."""
+    cfg = capi.KrConfig()
+    cfg.abi_version = 2
+    cfg.N, cfg.NT, cfg.K, cfg.L, cfg.G = 2, 4, 1, 1, 1
+    cfg.spin_timeout_ms = -12345              # what an unzeroed v2 `reserved` might hold
+    cfg.options = C.cast(C.c_void_p(0x10), C.c_char_p)   # a wild pointer: must never be dereferenced
+    h = C.c_void_p()
+    assert lib.kr_create(C.byref(cfg), C.byref(h)) == capi.KR_ERR_INVALID and not h
+    assert b"abi_version 2 != 3" in lib.kr_last_error(None)
 
 
 def test_config_struct_layout():
-    # mirrors `struct kr_config` (include/krotov_hip.h, ABI v2): 6 ints, 5 pointers, flags (+ pad), double, 4 ints,
+    # mirrors `struct kr_config` (include/krotov_hip.h, ABI v3): 6 ints, 5 pointers, flags (+ pad), double, 4 ints,
     # 4 + 8 ints of v2, control_poly (2 ints + pointer), spin bound + pad, options pointer, 4 reserved
     assert C.sizeof(capi.KrConfig) == 24 + 40 + 4 + 4 + 8 + 16 + 16 + 32 + 16 + 8 + 8 + 16
     assert capi.KrConfig.options.offset == 168 and capi.KrConfig.spin_timeout_ms.offset == 160

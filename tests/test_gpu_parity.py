@@ -568,14 +568,15 @@ def test_rowsplit_pair_mode_agrees_with_single_mode_and_oracle(oracle_c, monkeyp
         p = wl.dense_problem(130, 35, 40, 1, 193, 0.02, 0.2)
     r_single = 2 if case.startswith("np128") else 4
     res = {}
+    ref = _oracle_iteration(None, p)   # (SciPy twin: one expm per step; each mode meets it BEFORE the modes are compared)
     for mode in ["0", "1"]:
         monkeypatch.setenv("KROTOV_HIP_RS_PAIR", mode)
-        res[mode], info = _iterate(p)
+        res[mode], info = _iterate_against_oracle(ref, p, "%s, KROTOV_HIP_RS_PAIR=%s" % (case, mode))
         assert info["rowsplit_R"] == (2 * r_single if mode == "1" else r_single) and info["KT"] == (2 if mode == "1" else 1), info
     assert _rel(res["1"][0], res["0"][0]) < 1e-12
     assert np.max(np.abs(res["1"][2] - res["0"][2])) < 1e-12 * max(1.0, np.max(np.abs(res["0"][2])))
     monkeypatch.setenv("KROTOV_HIP_RS_PAIR", "1")
-    if case != "liouvillian":     # (the C oracle; the Liouvillian against the SciPy twin is test_gpu_parity_fullsize.py's)
+    if case in ("n130", "np128_local"):     # (and the C oracle -- the reference's execution order -- on two of the shapes)
         _run_case(oracle_c, p, check_storage=False)
 
 
@@ -720,22 +721,61 @@ def test_economized_step_polynomial(oracle_c, monkeypatch):
     _run_case(oracle_c, p)
 
 
+def _oracle_iteration(oc, p):
+    """Forward sweep + one iteration of the oracle.  oc = the C oracle (the reference's execution order: one expm per trajectory and
+    step; all host threads, the sums keep the serial order) or None = the NumPy/SciPy twin (one expm per step, shared by the
+    trajectories: the large shared-generator cases)."""
+    if oc is None:
+        import krotov_oracle as o
+        psiT_o, _ = o.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False)
+        _, _, chiT = wl.chi_and_JT(p["functional"], psiT_o, p["tgt"])
+        eps_o, ga_o, psiT1_o, X_o, _ = o.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT)
+    else:
+        nt = oc.max_threads()
+        psiT_o, _ = oc.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False, nthreads=nt)
+        _, _, chiT = wl.chi_and_JT(p["functional"], psiT_o, p["tgt"])
+        eps_o, ga_o, psiT1_o, X_o, _ = oc.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT, nthreads=nt)
+    return dict(psiT=psiT_o, chiT=chiT, eps_new=eps_o, g_a_int=ga_o, psiT1=psiT1_o, X0=X_o[0].copy())
+
+
+def _iterate_against_oracle(ref, p, label):
+    """One forward sweep + one iteration on a fresh handle, EVERY stage against the oracle (`ref` = _oracle_iteration(oc, p)), so that a
+    disagreement between two kernel variants names the wrong one and the sweep it comes from; on a mismatch the same handle repeats
+    the backward sweep, which tells a transient fault from a persistent one.  Returns what _iterate returns."""
+    K = p["psi0"].shape[0]
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        e_fw = np.max(np.abs(psiT - ref["psiT"]))
+        out = eng.iteration(p["eps"], ref["chiT"], p["S"], p["lam"])
+        X0 = np.array([eng.read_storage("bw", k, 0) for k in range(K)])
+        scale = max(1.0, np.max(np.abs(ref["X0"])))
+        e_bw = np.max(np.abs(X0 - ref["X0"])) / scale
+        e_eps, e_psi = _rel(out[0], ref["eps_new"]), np.max(np.abs(out[2] - ref["psiT1"]))
+        info, plan = eng.info(), eng.plan()
+        if not (e_fw < TOL_STATE and e_bw < TOL_STATE and e_eps < TOL_PULSE and e_psi < 1e-9):
+            eng.backward(p["eps"], ref["chiT"])   # the same handle once more: transient or persistent?
+            X0b = np.array([eng.read_storage("bw", k, 0) for k in range(K)])
+            pytest.fail("%s against the oracle: forward psi(T) %.2e, backward X[0] %.2e (same handle again: %.2e), pulses %.2e, psi(T)' %.2e; %s"
+                        % (label, e_fw, e_bw, np.max(np.abs(X0b - ref["X0"])) / scale, e_eps, e_psi, plan))
+    return out, info
+
+
 def test_rowsplit_one_control_instantiation(oracle_c, monkeypatch):
     """Row-split kernels (64 < N <= 256) with L = 1 run an instantiation compiled for one control (fewer accumulators, four columns in
-    flight in the streaming passes); it must agree with the two-control kernels (KROTOV_HIP_RS_LMAX1=0) far inside the parity
-    tolerances and with the oracle at them -- Hermitian and non-Hermitian generators, N that does not fill the padded size, K that
-    gives R = 4 and R = 8 workgroups per trajectory."""
+    flight in the streaming passes).  BOTH instantiations (KROTOV_HIP_RS_LMAX1 = 0 / 1) must meet the oracle at the parity tolerances
+    at every stage -- checked first, so that a failure names the instantiation and the sweep -- and then agree with each other far
+    inside them: Hermitian and non-Hermitian generators, N that does not fill the padded size, K that gives R = 4 and R = 8
+    workgroups per trajectory."""
     cases = [wl.dense_problem(100, 40, 6, 1, 191, 0.02, 2.0), wl.dense_problem(256, 36, 24, 1, 192, 0.01, 2.0),
              wl.dense_problem(130, 35, 40, 1, 193, 0.02, 5.0)]
     cases[2]["H0"] = cases[2]["H0"] - 0.03j * np.diag(np.random.default_rng(5).uniform(0, 1, 130))
     for ci, p in enumerate(cases):
         res = {}
+        ref = _oracle_iteration(oracle_c, p)
         for mode in ["0", "1"]:
             monkeypatch.setenv("KROTOV_HIP_RS_LMAX1", mode)
-            res[mode], info = _iterate(p)
+            res[mode], info = _iterate_against_oracle(ref, p, "case %d, KROTOV_HIP_RS_LMAX1=%s" % (ci, mode))
             assert info["rowsplit_R"] > 0 and info["LMAX"] == (1 if mode == "1" else 2), info
         assert _rel(res["1"][0], res["0"][0]) < 1e-12, ci
         assert np.max(np.abs(res["1"][2] - res["0"][2])) < 1e-12 * max(1.0, np.max(np.abs(res["0"][2]))), ci
-    monkeypatch.setenv("KROTOV_HIP_RS_LMAX1", "1")
-    _run_case(oracle_c, cases[0], check_storage=False)
-    _run_case(oracle_c, cases[2], check_storage=False)

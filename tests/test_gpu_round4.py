@@ -1,0 +1,48 @@
+"""GPU tests of round 4: the rigorous norm bounds behind the step polynomials."""
+import numpy as np
+import pytest
+
+import krotov_jl_amd as kr
+from krotov_jl_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def _unitary(rng, n):
+    q, r = np.linalg.qr(rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n)))
+    return q * (np.diag(r) / np.abs(np.diag(r)))
+
+
+def test_norm_bounds_are_upper_bounds_within_a_third_of_a_percent():
+    """kr_get_norm_bounds: the 2-norm bounds of H0, H_l that set every step polynomial's degree and the interval of the economized
+    polynomial are UPPER bounds (||A||_2 <= ||(A^H A)^p||_F^(1/(2p)), kr_norm.hip), at most 0.3 % above the norm -- also where a
+    power iteration stalls: a clustered top of the spectrum at N > 256, a top singular vector (nearly) orthogonal to the start
+    vector the host iteration of rounds 1-3 used, non-normal operators, operators of very different scale, a zero operator."""
+    rng = np.random.default_rng(404)
+    cases = []
+    for n in (5, 16, 64, 130):
+        cases.append(("hermitian %d" % n, wl.random_hermitian(rng, n), wl.random_hermitian(rng, n) * 3.7))
+    n = 300
+    u = _unitary(rng, n)
+    ev = np.r_[1.0 - 1e-7 * np.arange(40), rng.uniform(-0.9, 0.9, n - 40)]     # forty eigenvalues within 4e-6 of the top
+    cases.append(("clustered top, N = 300", (u * ev) @ u.conj().T, wl.random_hermitian(rng, n) * 1e-3))
+    # the old start vector x_i = 1 + 0.37 sin(1.7 i + 0.3) + 0.21i cos(2.3 i): top eigenvector orthogonal to it, second one 1 % below
+    n = 280
+    x = 1.0 + 0.37 * np.sin(1.7 * np.arange(n) + 0.3) + 0.21j * np.cos(2.3 * np.arange(n))
+    x /= np.linalg.norm(x)
+    v = rng.normal(size=n) + 1j * rng.normal(size=n)
+    v -= x * np.vdot(x, v)
+    v /= np.linalg.norm(v)
+    cases.append(("top eigenvector orthogonal to the old start vector", np.outer(v, v.conj()) + 0.99 * np.outer(x, x.conj()), np.outer(x, x.conj()) * 2.0))
+    g = rng.normal(size=(48, 48)) + 1j * rng.normal(size=(48, 48))               # non-normal
+    cases.append(("non-normal 48", g, np.triu(g, 1) * 1e6))
+    cases.append(("zero control operator", wl.random_hermitian(rng, 20), np.zeros((20, 20), complex)))
+    for name, H0, H1 in cases:
+        N = H0.shape[0]
+        with kr.HipEngine(H0, H1[None], np.linspace(0.0, 1.0, 5), 2) as eng:
+            b = eng.norm_bounds()[0]
+        for bound, M in zip(b, (H0, H1)):
+            exact = np.linalg.norm(M, 2)
+            assert bound >= exact * (1.0 - 1e-12), (name, bound, exact)
+            assert bound <= exact * 1.003 + 1e-300, (name, bound, exact)
+        print("%-52s N=%3d bounds / norms: %.6f %.6f" % (name, N, b[0] / np.linalg.norm(H0, 2), b[1] / max(np.linalg.norm(H1, 2), 1e-300)))
