@@ -55,6 +55,8 @@ struct KrSweepArgs {
     unsigned long long *peer_xmail[8]; // every rank's xmail (peer_xmail[rank] == xmail)
     double2 *U;              // [NT][NP*NP] precomputed step propagators, thread-major (kr_device_prop.h), or nullptr
     unsigned long long *gmail; // row-split kernels: per-trajectory vector mailbox [tiles][2][NP][4] granules
+    int rs_fault;              // diagnostics (option RS_FAULT=1): workgroup 1 flips one bit of its copy of the final state vector, so that the
+                               // coherence check of the group (kr_rowsplit_check) has something to find (tests)
     int rs_sets;               // row-split PAIR mode: pairs a group of workgroups carries in turn (1: one pair per group)
     double2 *rs_scratch;       // ... and the per-workgroup scratch of their state vectors [P][KR_PAIR_MAX_SETS][2][NP] (rs_sets > 1)
     unsigned epoch_base2;    // tag base of the vector mailbox for this launch

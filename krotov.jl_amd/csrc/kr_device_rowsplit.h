@@ -511,6 +511,30 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     }
     if (stamp && tid == 0) { a.debug[0] = tS; a.debug[1] = tD; a.debug[2] = tG; a.debug[3] = tX; a.debug[7] = nG; a.debug[5] = box.tpoll; a.debug[6] = box.npass; }
 #undef KR_STAMP
+    if constexpr (R > 1) {
+        // Coherence word of the group (round 4): the R workgroups of a trajectory must end the sweep with bitwise identical copies
+        // of its state vector -- every element they hold went through the all-gather.  Each posts a position-sensitive checksum of
+        // its LDS copy behind the mailboxes (the XCC-id table's slots: their job ended at kernel start); kr_rowsplit_check
+        // (krotov_hip.hip) compares them after the launch and turns a difference into a status instead of a silently wrong sweep.
+        __shared__ unsigned long long scs[G::THREADS / 64];
+        if (a.rs_fault && wg == 1 && tid == 0) { sx[cur][0].x = __longlong_as_double(__double_as_longlong(sx[cur][0].x) ^ 2ll); }   // (tests: a fault to find)
+        if (a.rs_fault) __syncthreads();
+        unsigned long long cs = 0ull;
+        for (int e = tid; e < NP; e += G::THREADS) {
+            const double2 v = sx[cur][e + e / JS];
+            const unsigned long long bx = (unsigned long long)__double_as_longlong(v.x), by = (unsigned long long)__double_as_longlong(v.y);
+            const int r1 = e & 63, r2 = (e * 7 + 13) & 63;
+            cs ^= ((bx << r1) | (r1 ? bx >> (64 - r1) : 0ull)) ^ ((by << r2) | (r2 ? by >> (64 - r2) : 0ull));
+        }
+        for (int o = 1; o < 64; o <<= 1) cs ^= __shfl_xor(cs, o, 64);
+        if (lane == 0) scs[tid >> 6] = cs;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long all = 0x9E3779B97F4A7C15ull;   // (never zero by accident: a zero slot means "not posted")
+            for (int w = 0; w < G::THREADS / 64; ++w) all = (all << 1 | all >> 63) ^ scs[w];
+            __hip_atomic_store((kr_gu64 *)(a.gmail + (size_t)tiles * 2 * NP * 4) + wg, all | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (a.fin && owner && row_ok) a.fin[kbase + row] = make_double2(pr, pim);
     if (UPDATE && wg == 0 && tid == 0) {
 #pragma unroll

@@ -237,7 +237,7 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
 static const char *const kr_option_names[] = {
     "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
     "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "POLL_DELAY", "PRECOMP", "ROWSPLIT",
-    "RS512", "RS_BATCH", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
+    "RS512", "RS_BATCH", "RS_FAULT", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
 static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
     out.clear();
     if (!text) return true;
@@ -369,6 +369,18 @@ __global__ __launch_bounds__(64) void kr_econ_rows_kernel(const double *eps, con
         else if (lane == 31) v = (double)m;
         row[lane] = v;
     }
+}
+
+// After a single-mode row-split sweep (kr_rowsplit_sweep): the R workgroups of every trajectory posted a checksum of the state
+// vector they ended with; all R must agree (every element of every copy went through the all-gather).  A difference -- a stale or
+// torn element accepted by one member of the group -- becomes status code 6 instead of a silently wrong sweep.
+__global__ void kr_rowsplit_check(const unsigned long long *words, int tiles, int R, unsigned *status) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const unsigned long long ref = words[(size_t)t * R];
+    bool bad = (ref == 0ull);
+    for (int r = 1; r < R; ++r) bad = bad || (words[(size_t)t * R + r] != ref);
+    if (bad && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 6u; status[2] = (unsigned)t; }
 }
 
 __global__ void kr_tau_kernel(const double2 *tgt, const double2 *psi, double2 *tau, int N, int K) {
@@ -1369,6 +1381,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.gmail = h->gmail_d;
     a.xcd_group = h->xcd_group ? 1 : 0;
     a.rs_sets = h->rs_sets;
+    a.rs_fault = opt_int(h, "RS_FAULT", 0);
     a.rs_scratch = h->rs_scratch_d;
     a.pack_stride = h->pack_stride;
     a.Hdense = h->Hdense_fw;
@@ -1404,6 +1417,15 @@ static int rowsplit_prelaunch(kr_handle *h, KrSweepArgs &a) {
     HIPCHK(h, hipMemsetAsync(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long), h->stream));
     a.epoch_base2 = h->launch_id << 24;
     return KR_OK;   // (the status words are sticky: only check_status clears them)
+}
+
+// single-mode row-split sweeps end with a coherence word per workgroup (kr_rowsplit_sweep): compare them group by group
+static int rowsplit_postlaunch(kr_handle *h, int tiles) {
+    if (h->R <= 1) return KR_OK;
+    hipLaunchKernelGGL(kr_rowsplit_check, dim3((tiles + 255) / 256), dim3(256), 0, h->stream,
+                       h->gmail_d + (size_t)tiles * 2 * h->NP * 4, tiles, h->R, h->status_d);
+    HIPCHK(h, hipGetLastError());
+    return KR_OK;
 }
 
 // ---- polynomial step propagators (Chebyshev, Newton): per-step coefficient tables ------------------------
@@ -1647,9 +1669,13 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
                 a.P = nb * h->R;
                 a.xcd_group = (h->xcd_group && nb % 8 == 0) ? 1 : 0;
                 HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, 0, nb * h->R, h->stream, &a));
+                rc = rowsplit_postlaunch(h, nb);
+                if (rc) return rc;
             }
-        } else
-        HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 2 : 0, h->P, h->stream, &a));
+        } else {
+            HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 2 : 0, h->P, h->stream, &a));
+            if (!h->rs_pair) { rc = rowsplit_postlaunch(h, h->P / h->R); if (rc) return rc; }
+        }
     } else if (h->precomp) {
         // all N_T step propagators in parallel, then one matvec round per step.  N = 64: both on the matrix cores
         // (kr_expm_mfma64 writes the propagators as MFMA A operands, kr_mf_apply_sweep applies them, two trajectories per
@@ -1745,6 +1771,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
         if (rc) return rc;
         if (h->rs_turns > 0) a.rs_sets = h->rs_turns;
         HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_turns > 0 ? 5 : (h->rs_pair ? 3 : 1), h->P, h->stream, &a));
+        if (h->rs_turns == 0 && !h->rs_pair) { rc = rowsplit_postlaunch(h, h->P / h->R); if (rc) return rc; }
     } else
     {   // update kernel variant: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (kr_launch_np); N <= 64 only
         int kind = 1;
@@ -1844,6 +1871,9 @@ static int check_status(kr_handle *h) {
         if (st[1] == 5)
             return fail(h, KR_ERR_UNSUPPORTED, "update sweep: at step %u an updated control left the range the %s propagator was initialised for (5 x the guess amplitude, transform_control_ranges); results of this call are invalid -- use prop_method = TAYLOR or a larger lambda_a",
                         st[2], h->method == KR_PROP_CHEBY ? "Chebyshev" : "Newton");
+        if (st[1] == 6)
+            return fail(h, KR_ERR_INTERNAL, "row-split sweep: the %d workgroups that share trajectory tile %u ended the sweep with different copies of its state vector (an all-gather element was lost or accepted stale); results of this call are invalid",
+                        h->R, st[2]);
         const char *what = st[1] == 4 ? "cross-rank sum of the taus (J_T_sm)"
                          : st[1] == 2 ? "inter-GPU exchange of the update sweep"
                          : st[1] == 3 ? "row-split all-gather (the R workgroups of a trajectory)"
