@@ -76,6 +76,9 @@ struct kr_handle {
     unsigned *present_d = nullptr;
     // device buffers
     double2 *Hpack_fw = nullptr, *Hpack_bw = nullptr;
+    unsigned long long pack_sum[2] = {0ull, 0ull};   // checksums of the host copies of Hpack_fw / Hpack_bw (kr_pack_check)
+    unsigned long long *pack_words_d = nullptr;      // [2] running checksum + block counter of kr_pack_check
+    size_t pack_elems = 0;
     double *dt_d = nullptr, *eps_a = nullptr, *eps_b = nullptr, *S_d = nullptr, *lambda_d = nullptr, *gint_d = nullptr;
     double2 *psi0_d = nullptr, *tgt_d = nullptr, *psiT_d = nullptr, *chiT_d = nullptr, *X_d = nullptr, *Phi_d = nullptr;
     double2 *tau_d = nullptr, *tausum_d = nullptr;
@@ -236,7 +239,7 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
 // is the fallback for the lab.  kr_create rejects a name that is not in this list (a typo would otherwise be silently ignored).
 static const char *const kr_option_names[] = {
     "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
-    "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "POLL_DELAY", "PRECOMP", "ROWSPLIT",
+    "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "PACK_CHECK", "PACK_FAULT", "POLL_DELAY", "PRECOMP", "ROWSPLIT",
     "RS512", "RS_BATCH", "RS_FAULT", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
 static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
     out.clear();
@@ -368,6 +371,48 @@ __global__ __launch_bounds__(64) void kr_econ_rows_kernel(const double *eps, con
         else if (lane == 30) v = th;
         else if (lane == 31) v = (double)m;
         row[lane] = v;
+    }
+}
+
+// Integrity of the generator packs (round 4).  The packs are uploaded once at kr_create and read by every sweep of the handle's
+// life; a corrupted pack does not crash anything -- it propagates with a slightly wrong generator, smoothly and silently (the one
+// wrong result the driver ever recorded, GPUTEST_r03, had exactly that signature: a backward sweep -- the only reader of the adjoint
+// pack -- off by ~1e-3 per step, never reproduced).  So every sweep is preceded by one small launch that folds the pack it is about
+// to read into a position-sensitive 64-bit checksum (XOR of rotated words: order-independent, so plain atomics do) and compares
+// it with the checksum of the host copy taken at kr_create; a difference becomes status code 7 (KR_ERR_INTERNAL).
+__host__ __device__ static inline unsigned long long kr_pack_word(unsigned long long a, unsigned long long b, size_t i) {
+    const int r1 = (int)(i & 63), r2 = (int)((i * 7 + 13) & 63);
+    return ((a << r1) | (r1 ? a >> (64 - r1) : 0ull)) ^ ((b << r2) | (r2 ? b >> (64 - r2) : 0ull)) ^ ((unsigned long long)i * 0x9E3779B97F4A7C15ull);
+}
+static unsigned long long pack_checksum_host(const double2 *p, size_t n) {
+    unsigned long long cs = 0ull;
+    for (size_t i = 0; i < n; ++i) {
+        unsigned long long a, b;
+        memcpy(&a, &p[i].x, 8); memcpy(&b, &p[i].y, 8);
+        cs ^= kr_pack_word(a, b, i);
+    }
+    return cs;
+}
+// words: [0] running checksum, [1] blocks that have added theirs; both zeroed by the last block for the next use
+__global__ __launch_bounds__(256) void kr_pack_check(const double2 *p, size_t n, unsigned long long expect, unsigned long long *words, int which, unsigned *status) {
+    __shared__ unsigned long long sw[4];
+    unsigned long long cs = 0ull;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double2 v = p[i];
+        cs ^= kr_pack_word((unsigned long long)__double_as_longlong(v.x), (unsigned long long)__double_as_longlong(v.y), i);
+    }
+    for (int o = 1; o < 64; o <<= 1) cs ^= __shfl_xor(cs, o, 64);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = cs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicXor(words, sw[0] ^ sw[1] ^ sw[2] ^ sw[3]);
+        __threadfence();
+        if (atomicAdd(words + 1, 1ull) == (unsigned long long)gridDim.x - 1ull) {   // last block: every contribution is in
+            const unsigned long long got = atomicXor(words, 0ull);
+            if (got != expect && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 7u; status[2] = (unsigned)which; }
+            atomicExch(words, 0ull);
+            atomicExch(words + 1, 0ull);
+        }
     }
 }
 
@@ -841,7 +886,7 @@ extern "C" int kr_abi_version(void) { return KR_ABI_VERSION; }
 extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 static void free_all(kr_handle *h) {
-    void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
+    void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->pack_words_d, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d, h->skw_d,
                     h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1069,6 +1114,23 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
                 else pack_generator(N, NP, h->JQ, M, adj != 0, dst);
             }
         CHK(hipMemcpy(adj ? h->Hpack_bw : h->Hpack_fw, pack.data(), pack_elems * sizeof(double2), hipMemcpyHostToDevice));
+        CHK(hipDeviceSynchronize());   // (the host vector is refilled for the adjoint pack: the copy must have left it)
+        h->pack_sum[adj] = pack_checksum_host(pack.data(), pack_elems);
+    }
+    if (h->fast_ok) {
+        h->pack_elems = pack_elems;
+        if (opt_int(h, "PACK_CHECK", 1) != 0) {
+            CHK(dalloc(&h->pack_words_d, 2));
+            CHK(hipMemset(h->pack_words_d, 0, 2 * sizeof(unsigned long long)));
+        }
+        if (opt_int(h, "PACK_FAULT", 0) != 0) {   // diagnostics (tests): one mantissa bit of one element of the ADJOINT pack flipped after the upload
+            double2 v;
+            const size_t at = pack_elems / 3;
+            CHK(hipMemcpy(&v, h->Hpack_bw + at, sizeof v, hipMemcpyDeviceToHost));
+            unsigned long long b;
+            memcpy(&b, &v.x, 8); b ^= 1ull << 20; memcpy(&v.x, &b, 8);
+            CHK(hipMemcpy(h->Hpack_bw + at, &v, sizeof v, hipMemcpyHostToDevice));
+        }
     }
     if (h->mfma_sweep) {   // dense row-major copies, zero-padded to 64 x 64, for the A operands of the matrix-core sweep
         h->dense_stride = (size_t)(1 + L) * 64 * 64;
@@ -1635,9 +1697,20 @@ static int launch_update_stepped(kr_handle *h, const double *eps_guess_dev, doub
     return KR_OK;
 }
 
+// one small launch in front of a sweep: the pack it reads still is what kr_create uploaded (kr_pack_check)
+static int pack_precheck(kr_handle *h, bool adjoint) {
+    if (!h->pack_words_d || h->pack_elems == 0) return KR_OK;
+    const int blocks = (int)std::min<size_t>(256, (h->pack_elems + 2047) / 2048);
+    hipLaunchKernelGGL(kr_pack_check, dim3(blocks), dim3(256), 0, h->stream, adjoint ? h->Hpack_bw : h->Hpack_fw, h->pack_elems,
+                       h->pack_sum[adjoint ? 1 : 0], h->pack_words_d, adjoint ? 1 : 0, h->status_d);
+    HIPCHK(h, hipGetLastError());
+    return KR_OK;
+}
+
 static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool backward, const double2 *init, double2 *store, double2 *fin) {
     KrSweepArgs a;
     base_args(h, a);
+    if (!h->gen_known) { const int prc = pack_precheck(h, backward); if (prc) return prc; }
     a.Hpack = backward ? h->Hpack_bw : h->Hpack_fw;
     a.eps = eps_dev;
     a.init = init; a.store = store; a.fin = fin;
@@ -1745,6 +1818,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     KrSweepArgs a;
     base_args(h, a);
     if (calib_steps) { a.NT = calib_steps; a.world = 1; a.rank = 0; }  // calibration: first steps only, this GPU alone
+    else { const int prc = pack_precheck(h, false); if (prc) return prc; }
     a.Hpack = h->Hpack_fw;
     a.eps = eps_guess_dev;
     a.init = h->psi0_d; a.store = h->store_fw ? h->Phi_d : nullptr; a.fin = h->psiT_d;
@@ -1871,6 +1945,9 @@ static int check_status(kr_handle *h) {
         if (st[1] == 5)
             return fail(h, KR_ERR_UNSUPPORTED, "update sweep: at step %u an updated control left the range the %s propagator was initialised for (5 x the guess amplitude, transform_control_ranges); results of this call are invalid -- use prop_method = TAYLOR or a larger lambda_a",
                         st[2], h->method == KR_PROP_CHEBY ? "Chebyshev" : "Newton");
+        if (st[1] == 7)
+            return fail(h, KR_ERR_INTERNAL, "the %s generator pack on the device no longer matches the operators kr_create uploaded (checksum mismatch in front of a sweep): device memory was corrupted; results of this call are invalid -- create a new handle",
+                        st[2] ? "adjoint (backward-sweep)" : "forward");
         if (st[1] == 6)
             return fail(h, KR_ERR_INTERNAL, "row-split sweep: the %d workgroups that share trajectory tile %u ended the sweep with different copies of its state vector (an all-gather element was lost or accepted stale); results of this call are invalid",
                         h->R, st[2]);
@@ -1907,7 +1984,7 @@ static int one_forward(kr_handle *h, const double *eps, double *psiT_out) {
     HIPCHK(h, hipMemcpyAsync(h->eps_a, eps, pb, hipMemcpyHostToDevice, h->stream));
     int rc = launch_known(h, 0, h->eps_a, false, h->psi0_d, h->store_fw ? h->Phi_d : nullptr, h->psiT_d);
     if (rc) return rc;
-    if (h->rowsplit) { rc = check_status(h); if (rc) return rc; }   // the row-split all-gather has bounded spins
+    rc = check_status(h); if (rc) return rc;   // pack checksum; bounded spins of the row-split all-gather
     rc = download_states(h, psiT_out, h->psiT_d);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1925,7 +2002,7 @@ static int one_backward(kr_handle *h, const double *eps_guess, const double *chi
     if (rc) return rc;
     rc = launch_known(h, 1, h->eps_a, true, h->chiT_d, h->X_d, nullptr);
     if (rc) return rc;
-    if (h->rowsplit) { rc = check_status(h); if (rc) return rc; }
+    rc = check_status(h); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_X = true;
     return KR_OK;

@@ -70,3 +70,25 @@ def test_rowsplit_group_coherence_check_finds_a_planted_fault():
         with pytest.raises(kr.KrotovHipError) as ei:
             eng.iteration(p["eps"], chiT, p["S"], p["lam"])
         assert ei.value.code == kr._capi.KR_ERR_INTERNAL
+
+
+@pytest.mark.parametrize("shape", [(16, 30, 12, 2), (64, 20, 256, 2), (100, 6, 6, 1)])
+def test_generator_pack_integrity_check(shape):
+    """Every sweep is preceded by a checksum of the generator pack it is about to read (kr_pack_check) against the host copy taken at
+    kr_create.  A clean handle passes; with the diagnostics option PACK_FAULT=1 ONE mantissa bit of ONE element of the adjoint pack is
+    flipped after the upload: the forward sweep (forward pack) still runs, the backward sweep -- the only reader of the adjoint
+    pack -- must refuse with KR_ERR_INTERNAL instead of propagating with a slightly wrong generator."""
+    N, NT, K, L = shape
+    p = wl.dense_problem(N, NT, K, L, 4200 + N, 0.05, 2.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, options={"PACK_FAULT": 1}) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
+        with pytest.raises(kr.KrotovHipError) as ei:
+            eng.backward(p["eps"], chiT)
+        assert ei.value.code == kr._capi.KR_ERR_INTERNAL and "adjoint" in str(ei.value) and "checksum" in str(ei.value), str(ei.value)
+        assert np.max(np.abs(eng.forward(p["eps"]) - psiT)) == 0.0      # the forward pack is intact: same bits as before
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:         # and a clean handle runs a whole iteration
+        eng.set_initial_states(p["psi0"])
+        eng.forward(p["eps"])
+        eng.iteration(p["eps"], chiT, p["S"], p["lam"])
