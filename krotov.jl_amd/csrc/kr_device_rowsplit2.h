@@ -674,6 +674,32 @@ kr_next_set:
 #pragma unroll
         for (int q = 0; q < KP; ++q) a.fin[kbase[q] + row] = make_double2(pr[q], pim[q]);
     }
+    if constexpr (!MULTI) {
+        // Coherence word of the group (round 4; kr_rowsplit_sweep has the same): the 2R workgroups of a pair end the sweep with bitwise
+        // identical copies of BOTH state vectors; each posts a position-sensitive checksum of its LDS copies in its slot of the XCC-id
+        // table, kr_rowsplit_check compares them after the launch.
+        __shared__ unsigned long long scs[T / 64];
+        if (a.rs_fault && wg == 1 && tid == 0) sx[1][cur][0].x = __longlong_as_double(__double_as_longlong(sx[1][cur][0].x) ^ 2ll);   // (tests: a fault to find)
+        if (a.rs_fault) __syncthreads();
+        unsigned long long cs = 0ull;
+#pragma unroll
+        for (int q = 0; q < KP; ++q) {
+            for (int e = tid; e < NP; e += T) {
+                const double2 v = sx[q][cur][e];
+                const unsigned long long bx = (unsigned long long)__double_as_longlong(v.x), by = (unsigned long long)__double_as_longlong(v.y);
+                const int i = q * NP + e, r1 = i & 63, r2 = (i * 7 + 13) & 63;
+                cs ^= ((bx << r1) | (r1 ? bx >> (64 - r1) : 0ull)) ^ ((by << r2) | (r2 ? by >> (64 - r2) : 0ull));
+            }
+        }
+        for (int o = 1; o < 64; o <<= 1) cs ^= __shfl_xor(cs, o, 64);
+        if (lane == 0) scs[wave] = cs;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long all = 0x9E3779B97F4A7C15ull;
+            for (int w = 0; w < T / 64; ++w) all = (all << 1 | all >> 63) ^ scs[w];
+            __hip_atomic_store((kr_gu64 *)(a.gmail + (size_t)tiles * KP * 2 * NP * 4) + wg, all | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     }   // known-pulse sets
     if constexpr (MULTI && !UPDATE) { if (++kset < KS) goto kr_next_set; }
     (void)kset; (void)KS;
