@@ -57,7 +57,11 @@ enum kr_status {
     KR_ERR_TIMEOUT = 5,     /* an in-kernel bounded spin gave up (device status word set)      */
     KR_ERR_STATE = 6,       /* call order violated (e.g. update before backward)               */
     KR_ERR_INTERNAL = 7     /* a C++ exception (std::bad_alloc, std::system_error, ...) was caught at the
-                               boundary; the message names it.  Nothing propagates into the caller.     */
+                               boundary (the message names it; nothing propagates into the caller), or an
+                               integrity check of a sweep failed: the generator pack on the device no longer
+                               matches what kr_create uploaded, or the workgroups that share a trajectory
+                               ended a row-split sweep with different copies of its state vector.  The
+                               results of that call are invalid; the message says which check.           */
 };
 
 enum kr_flags {

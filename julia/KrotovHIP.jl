@@ -282,6 +282,13 @@ read_storage(wrk::Krotov.KrotovWrk, which::Symbol, k::Int, n::Int) = read_storag
 """One line: which kernels carry this workspace's sweeps (kr_plan_description)."""
 plan(eng::Engine) = unsafe_string(ccall((:kr_plan_description, LIB), Cstring, (Ptr{Cvoid},), eng.handle))
 
+"""Upper bounds of ‖H₀‖₂, ‖H_l‖₂ per generator, `(1 + L) × G` (kr_get_norm_bounds): what sets the degree of every step polynomial."""
+function norm_bounds(eng::Engine, L::Int, G::Int = 1)
+    out = Matrix{Float64}(undef, 1 + L, G)
+    GC.@preserve out check(eng.handle, ccall((:kr_get_norm_bounds, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), eng.handle, out))
+    return out
+end
+
 """An MPI all-reduce as the per-step exchange (kr_config.exchange = 3): `fn(buf::Vector{Float64})` must sum in place
 over all ranks.  The @cfunction must stay alive as long as the engine does."""
 function set_exchange_callback!(eng::Engine, fn)

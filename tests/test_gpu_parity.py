@@ -756,8 +756,11 @@ def _iterate_against_oracle(ref, p, label):
         if not (e_fw < TOL_STATE and e_bw < TOL_STATE and e_eps < TOL_PULSE and e_psi < 1e-9):
             eng.backward(p["eps"], ref["chiT"])   # the same handle once more: transient or persistent?
             X0b = np.array([eng.read_storage("bw", k, 0) for k in range(K)])
-            pytest.fail("%s against the oracle: forward psi(T) %.2e, backward X[0] %.2e (same handle again: %.2e), pulses %.2e, psi(T)' %.2e; %s"
-                        % (label, e_fw, e_bw, np.max(np.abs(X0b - ref["X0"])) / scale, e_eps, e_psi, plan))
+            import os
+            env = {k: v for k, v in os.environ.items() if k.startswith("KROTOV_HIP")}
+            pytest.fail("%s against the oracle: forward psi(T) %.2e, backward X[0] %.2e (same handle again: %.2e), pulses %.2e, psi(T)' %.2e; %s; "
+                        "norm bounds %s; environment %s" % (label, e_fw, e_bw, np.max(np.abs(X0b - ref["X0"])) / scale, e_eps, e_psi, plan,
+                                                          np.array2string(eng.norm_bounds(), precision=6), env))
     return out, info
 
 

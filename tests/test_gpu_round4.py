@@ -93,3 +93,45 @@ def test_generator_pack_integrity_check(shape):
         eng.set_initial_states(p["psi0"])
         eng.forward(p["eps"])
         eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+
+
+def test_handles_of_different_problems_in_turn():
+    """A result must not depend on what the PREVIOUS handle left behind (recycled device memory, caches, mailboxes): six handles --
+    three row-split shapes, one- and two-control instantiations -- in turn, three times over, every forward sweep and iteration
+    against the SciPy twin at the parity tolerances and bitwise equal to the same handle's first run."""
+    import os
+    import krotov_oracle as o
+    cases = [wl.dense_problem(100, 40, 6, 1, 191, 0.02, 2.0), wl.dense_problem(256, 36, 24, 1, 192, 0.01, 2.0),
+             wl.dense_problem(130, 35, 40, 1, 193, 0.02, 5.0)]
+    cases[2]["H0"] = cases[2]["H0"] - 0.03j * np.diag(np.random.default_rng(5).uniform(0, 1, 130))
+    refs = []
+    for p in cases:
+        psiT, _ = o.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False)
+        _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
+        eps_new, _, psiT1, _, _ = o.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT)
+        refs.append((psiT, chiT, eps_new, psiT1))
+    first = {}
+    old = os.environ.get("KROTOV_HIP_RS_LMAX1")
+    try:
+        for rep in range(3):
+            for ci, p in enumerate(cases):
+                for mode in ("0", "1"):
+                    os.environ["KROTOV_HIP_RS_LMAX1"] = mode
+                    K = p["psi0"].shape[0]
+                    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+                        eng.set_initial_states(p["psi0"])
+                        psiT = eng.forward(p["eps"])
+                        eps_new, ga, psiT1 = eng.iteration(p["eps"], refs[ci][1], p["S"], p["lam"])
+                    assert np.max(np.abs(psiT - refs[ci][0])) < 1e-11, (rep, ci, mode)
+                    assert np.max(np.abs(eps_new - refs[ci][2])) < 1e-10 * np.max(np.abs(refs[ci][2])), (rep, ci, mode)
+                    assert np.max(np.abs(psiT1 - refs[ci][3])) < 1e-9, (rep, ci, mode)
+                    key = (ci, mode)
+                    if key not in first:
+                        first[key] = (psiT, eps_new, psiT1)
+                    else:
+                        assert all(np.array_equal(a, b) for a, b in zip(first[key], (psiT, eps_new, psiT1))), (rep, ci, mode)
+    finally:
+        if old is None:
+            os.environ.pop("KROTOV_HIP_RS_LMAX1", None)
+        else:
+            os.environ["KROTOV_HIP_RS_LMAX1"] = old
