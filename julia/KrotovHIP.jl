@@ -48,7 +48,7 @@ using QuantumControl.QuantumPropagators.Interfaces: supports_inplace
 const LIB = get(ENV, "KROTOV_HIP_LIB", joinpath(@__DIR__, "..", "krotov.jl_amd", "lib", "libkrotov_hip.so"))
 const KR_ABI_VERSION = Int32(3)
 
-# struct kr_config (include/krotov_hip.h, ABI v2) -- field for field
+# struct kr_config (include/krotov_hip.h, ABI v3) -- field for field (tests/test_julia_shim_static.py compares it with the ctypes mirror)
 struct KrConfig
     abi_version::Int32
     N::Int32
