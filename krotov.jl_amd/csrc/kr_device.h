@@ -1102,6 +1102,29 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 
         // ---- pulse update (optimize.jl:351-358), identical on every workgroup ---------------
         double e[LMAX], de[LMAX];
+        // H(eps_new) = H(eps_guess) + sum_l (eps_new - eps_guess)_l H_l   (H(eps_guess) was formed before phase A)
+        auto update_E = [&]() {
+#pragma unroll
+            for (int jj = 0; jj < JS; ++jj) {
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    Er[jj] = fma(de[l], Hr[1 + l][jj], Er[jj]);
+                    Ei[jj] = fma(de[l], Hi[1 + l][jj], Ei[jj]);
+                }
+            }
+        };
+        double vr[KT], vi[KT];
+        auto form_v = [&](const double fsv, const bool store) {   // v = -i fs (H(eps_new) psi) = -i fs (b + sum de_l a_l): no matvec
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+                double wr = a0r[q], wi = a0i[q];
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) { wr = fma(de[l], alr[q][l], wr); wi = fma(de[l], ali[q][l], wi); }
+                vr[q] = fsv * wi;   // -i (wr + i wi) = wi - i wr
+                vi[q] = -fsv * wr;
+                if (store && writer) sy[0][q * SG + team][pi_] = make_double2(vr[q], vi[q]);
+            }
+        };
         double theta = gx.nrm[0];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
@@ -1123,31 +1146,17 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         const KrEcon eco = kr_econ_select(ec, theta, s, m);
         const double my_g = eco.on ? ec : my_rinv;   // Horner ratios of this step, lane j holds g_j
 
-        // H(eps_new) = H(eps_guess) + sum_l (eps_new - eps_guess)_l H_l   (H(eps_guess) was formed before phase A)
-#pragma unroll
-        for (int jj = 0; jj < JS; ++jj) {
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) {
-                Er[jj] = fma(de[l], Hr[1 + l][jj], Er[jj]);
-                Ei[jj] = fma(de[l], Hi[1 + l][jj], Ei[jj]);
-            }
-        }
-
         // ---- phase B: psi <- exp(-i H dt) psi.  The first application H(eps_new) psi = b + sum de_l a_l
         //      is already known, so sub-step 0 costs m-1 matvecs:
         //      psi' = psi + y1,  y_m = v,  y_{j-1} = v + (-i fs / j) H y_j,  v = -i fs (H psi)
         const double fs = (s == 1) ? dt : dt / (double)s;
         {
-            double vr[KT], vi[KT];
-#pragma unroll
-            for (int q = 0; q < KT; ++q) {
-                double wr = a0r[q], wi = a0i[q];
-#pragma unroll
-                for (int l = 0; l < LMAX; ++l) { wr = fma(de[l], alr[q][l], wr); wi = fma(de[l], ali[q][l], wi); }
-                vr[q] = fs * wi;   // -i (wr + i wi) = wi - i wr
-                vi[q] = -fs * wr;
-                if (m > 1 && writer) sy[0][q * SG + team][pi_] = make_double2(vr[q], vi[q]);
-            }
+            form_v(fs, m > 1);
+            // (round 4: H(eps_new) is formed BEHIND the LDS write of v, whose latency then runs under these 32 FMAs: C3 5.24 -> 5.19 us
+            //  per step, same box -- left to itself the compiler kept the source order.  Moving MORE behind it -- the running integral,
+            //  theta, the plan, the economized row: nothing waits for them -- measured slower at every N: 5.19 -> 5.30, C2 3.22 -> 3.33)
+            __builtin_amdgcn_sched_barrier(0);
+            update_E();
             if (m > 1) kr_team_sync<RT>();
             // memory wave: start fetching chi(t_{n+1}); it lands while the Taylor rounds run
             if (memwave && n + 1 + HERM < NT) {
