@@ -610,6 +610,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
         __syncthreads();
     }
     if (tid < KR_RS_MAX_TURNS) scnt[tid] = 0u;
+    unsigned long long coh = 0ull;   // this thread's share of the group's coherence word (posted at the end)
     double gint[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) gint[l] = 0.0;
@@ -747,6 +748,14 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
             }
             if (a.store && owner && row_ok) a.store[(size_t)(n + 1) * slab + kbase + row] = make_double2(pr, pim);
             for (int e = tid; e < NP; e += T) if (e < N) vscr[(size_t)s * NP + e] = sx[cur][e + e / JS];
+            if (n == NT - 1) {   // coherence word of the group (see kr_rowsplit_sweep): the final vector of every set this group carries
+                for (int e = tid; e < NP; e += T) {
+                    const double2 v = sx[cur][e + e / JS];
+                    const unsigned long long bx = (unsigned long long)__double_as_longlong(v.x), by = (unsigned long long)__double_as_longlong(v.y);
+                    const int i = s * NP + e, r1 = i & 63, r2 = (i * 7 + 13) & 63;
+                    coh ^= ((bx << r1) | (r1 ? bx >> (64 - r1) : 0ull)) ^ ((by << r2) | (r2 ? by >> (64 - r2) : 0ull));
+                }
+            }
             if (tid == 0) scnt[s] = box.counter;
             if (n == NT - 1 && a.fin && owner && row_ok) a.fin[kbase + row] = make_double2(pr, pim);
             // The scratch vector is written by all threads here and read back by OTHER threads of the same workgroup in load_set
@@ -761,6 +770,18 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     if (wg == 0 && tid == 0) {
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
+    }
+    {
+        __shared__ unsigned long long scs[T / 64];
+        if (a.rs_fault && wg == 1 && tid == 0) coh ^= 2ull;   // (tests: a fault to find)
+        for (int o = 1; o < 64; o <<= 1) coh ^= __shfl_xor(coh, o, 64);
+        if (lane == 0) scs[tid >> 6] = coh;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long all = 0x9E3779B97F4A7C15ull;
+            for (int w = 0; w < T / 64; ++w) all = (all << 1 | all >> 63) ^ scs[w];
+            __hip_atomic_store((kr_gu64 *)(a.gmail + (size_t)tiles * S * 2 * NP * 4) + wg, all | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -429,6 +429,22 @@ __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepAr
 
     const int KS = (MULTI && !UPDATE) ? S : 1;   // known-pulse sweeps: one whole sweep per set
     int kset = 0;
+    // Coherence word of the group (round 4; kr_rowsplit_sweep has the same): the 2R workgroups of a pair end the sweep with bitwise
+    // identical copies of BOTH state vectors -- of every set they carry.  Each thread folds the final elements it can see into a
+    // position-sensitive checksum (kr_pair_fold), the workgroup posts the XOR in its slot of the XCC-id table behind the mailboxes,
+    // and kr_rowsplit_check (krotov_hip.hip) compares the members of every group after the launch.
+    unsigned long long coh = 0ull;
+#define KR_PAIR_FOLD(set_, cur_)                                                                                       \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < KP; ++q_) {                                                            \
+            for (int e_ = tid; e_ < NP; e_ += T) {                                                                     \
+                const double2 v_ = sx[q_][cur_][e_];                                                                   \
+                const unsigned long long bx_ = (unsigned long long)__double_as_longlong(v_.x), by_ = (unsigned long long)__double_as_longlong(v_.y); \
+                const int i_ = ((set_) * KP + q_) * NP + e_, r1_ = i_ & 63, r2_ = (i_ * 7 + 13) & 63;                   \
+                coh ^= ((bx_ << r1_) | (r1_ ? bx_ >> (64 - r1_) : 0ull)) ^ ((by_ << r2_) | (r2_ ? by_ >> (64 - r2_) : 0ull)); \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
 kr_next_set:
     {
     if constexpr (MULTI && !UPDATE) if (kset > 0) {
@@ -651,6 +667,7 @@ kr_next_set:
             // the set's turn ends: psi(t_{n+1}) -- complete in every workgroup of the group -- goes to this workgroup's scratch
             const int q = tid >> 8, e = tid & 255;
             if (e < NP) vscr[((size_t)bs * KP + q) * NP + e] = sx[q][cur][e];
+            if (step == NT - 1) KR_PAIR_FOLD(bs, cur)
             if (tid < KP) scnt[bs][tid] = box[tid].counter;
             if (step == NT - 1 && a.fin && owner && row_ok) {
 #pragma unroll
@@ -674,34 +691,27 @@ kr_next_set:
 #pragma unroll
         for (int q = 0; q < KP; ++q) a.fin[kbase[q] + row] = make_double2(pr[q], pim[q]);
     }
-    if constexpr (!MULTI) {
-        // Coherence word of the group (round 4; kr_rowsplit_sweep has the same): the 2R workgroups of a pair end the sweep with bitwise
-        // identical copies of BOTH state vectors; each posts a position-sensitive checksum of its LDS copies in its slot of the XCC-id
-        // table, kr_rowsplit_check compares them after the launch.
-        __shared__ unsigned long long scs[T / 64];
-        if (a.rs_fault && wg == 1 && tid == 0) sx[1][cur][0].x = __longlong_as_double(__double_as_longlong(sx[1][cur][0].x) ^ 2ll);   // (tests: a fault to find)
+    if constexpr (!(MULTI && UPDATE)) {
+        if (a.rs_fault && wg == 1 && tid == 0 && kset == 0) sx[1][cur][0].x = __longlong_as_double(__double_as_longlong(sx[1][cur][0].x) ^ 2ll);   // (tests: a fault to find)
         if (a.rs_fault) __syncthreads();
-        unsigned long long cs = 0ull;
-#pragma unroll
-        for (int q = 0; q < KP; ++q) {
-            for (int e = tid; e < NP; e += T) {
-                const double2 v = sx[q][cur][e];
-                const unsigned long long bx = (unsigned long long)__double_as_longlong(v.x), by = (unsigned long long)__double_as_longlong(v.y);
-                const int i = q * NP + e, r1 = i & 63, r2 = (i * 7 + 13) & 63;
-                cs ^= ((bx << r1) | (r1 ? bx >> (64 - r1) : 0ull)) ^ ((by << r2) | (r2 ? by >> (64 - r2) : 0ull));
-            }
-        }
-        for (int o = 1; o < 64; o <<= 1) cs ^= __shfl_xor(cs, o, 64);
-        if (lane == 0) scs[wave] = cs;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long all = 0x9E3779B97F4A7C15ull;
-            for (int w = 0; w < T / 64; ++w) all = (all << 1 | all >> 63) ^ scs[w];
-            __hip_atomic_store((kr_gu64 *)(a.gmail + (size_t)tiles * KP * 2 * NP * 4) + wg, all | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        KR_PAIR_FOLD(kset, cur)
     }
     }   // known-pulse sets
     if constexpr (MULTI && !UPDATE) { if (++kset < KS) goto kr_next_set; }
     (void)kset; (void)KS;
+#undef KR_PAIR_FOLD
+    {
+        __shared__ unsigned long long scs[T / 64];
+        if (MULTI && UPDATE && a.rs_fault && wg == 1 && tid == 0) coh ^= 2ull;   // (tests: a fault to find)
+        for (int o = 1; o < 64; o <<= 1) coh ^= __shfl_xor(coh, o, 64);
+        __syncthreads();
+        if (lane == 0) scs[wave] = coh;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long all = 0x9E3779B97F4A7C15ull;   // (never zero by accident: a zero slot means "not posted")
+            for (int w = 0; w < T / 64; ++w) all = (all << 1 | all >> 63) ^ scs[w];
+            __hip_atomic_store((kr_gu64 *)(a.gmail + (size_t)tiles * S * KP * 2 * NP * 4) + wg, all | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (UPDATE && wg == 0 && tid == 0) a.g_a_int[0] = gint;
 }

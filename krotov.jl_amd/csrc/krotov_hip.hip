@@ -1482,11 +1482,12 @@ static int rowsplit_prelaunch(kr_handle *h, KrSweepArgs &a) {
 }
 
 // single-mode row-split sweeps end with a coherence word per workgroup (kr_rowsplit_sweep): compare them group by group
-// (tiles = groups of R workgroups in the launch; each carries KT trajectories -- 2 in pair mode -- whose mailboxes lie in front of the words)
-static int rowsplit_postlaunch(kr_handle *h, int tiles) {
+// (tiles = groups of R workgroups in the launch; each carries KT trajectories -- 2 in pair mode --, `sets` of them in turn, whose
+//  mailboxes lie in front of the words)
+static int rowsplit_postlaunch(kr_handle *h, int tiles, int sets = 1) {
     if (h->R <= 1) return KR_OK;
     hipLaunchKernelGGL(kr_rowsplit_check, dim3((tiles + 255) / 256), dim3(256), 0, h->stream,
-                       h->gmail_d + (size_t)tiles * h->KT * 2 * h->NP * 4, tiles, h->R, h->status_d);
+                       h->gmail_d + (size_t)tiles * sets * h->KT * 2 * h->NP * 4, tiles, h->R, h->status_d);
     HIPCHK(h, hipGetLastError());
     return KR_OK;
 }
@@ -1748,7 +1749,8 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
             }
         } else {
             HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_pair ? 2 : 0, h->P, h->stream, &a));
-            if (h->rs_sets <= 1) { rc = rowsplit_postlaunch(h, h->P / h->R); if (rc) return rc; }   // (pairs in turn: no coherence words yet)
+            rc = rowsplit_postlaunch(h, h->P / h->R, h->rs_sets);
+            if (rc) return rc;
         }
     } else if (h->precomp) {
         // all N_T step propagators in parallel, then one matvec round per step.  N = 64: both on the matrix cores
@@ -1846,7 +1848,8 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
         if (rc) return rc;
         if (h->rs_turns > 0) a.rs_sets = h->rs_turns;
         HIPCHK(h, h->launch_rs(h->LMAXv, h->NR, h->rs_turns > 0 ? 5 : (h->rs_pair ? 3 : 1), h->P, h->stream, &a));
-        if (h->rs_turns == 0 && h->rs_sets <= 1) { rc = rowsplit_postlaunch(h, h->P / h->R); if (rc) return rc; }
+        rc = rowsplit_postlaunch(h, h->P / h->R, h->rs_turns > 0 ? h->rs_turns : h->rs_sets);
+        if (rc) return rc;
     } else
     {   // update kernel variant: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (kr_launch_np); N <= 64 only
         int kind = 1;

@@ -48,16 +48,18 @@ def test_norm_bounds_are_upper_bounds_within_a_third_of_a_percent():
         print("%-52s N=%3d bounds / norms: %.6f %.6f" % (name, N, b[0] / np.linalg.norm(H0, 2), b[1] / max(np.linalg.norm(H1, 2), 1e-300)))
 
 
-@pytest.mark.parametrize("shape", [(100, 6, 6, 2), (130, 5, 40, 1), (300, 4, 3, 2)], ids=["single_np128", "pair_np256", "single_np512"])
+@pytest.mark.parametrize("shape", [(100, 6, 6, 2), (130, 5, 40, 1), (300, 4, 3, 2), (300, 4, 12, 2), (140, 4, 70, 1), (200, 4, 80, 2)],
+                         ids=["single_np128", "pair_np256", "single_np512", "turns_np512", "pair_sets_np256", "turns_np256"])
 def test_rowsplit_group_coherence_check_finds_a_planted_fault(shape):
-    """Row-split sweeps (single mode and pair mode) end with a coherence word per workgroup: the R workgroups of a trajectory (pair) must
+    """Row-split sweeps (single mode, pair mode, several sets or trajectories per group in turn) end with a coherence word per workgroup: the R workgroups of a trajectory (pair) must
     hold bitwise identical copies of its state vector(s) (every element went through the all-gather); kr_rowsplit_check compares them
     after the launch.  A clean run passes; with the diagnostics option RS_FAULT=1 workgroup 1 flips ONE mantissa bit of its copy at
     the end of the sweep and the call must fail with KR_ERR_INTERNAL naming the tile -- a silently wrong sweep becomes a loud one."""
     N, NT, K, L = shape
     p = wl.dense_problem(N, NT, K, L, 4101, 0.02, 2.0)
     with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
-        assert eng.info()["rowsplit_R"] > 1 and "in turn" not in eng.plan(), eng.plan()
+        assert eng.info()["rowsplit_R"] > 1, eng.plan()
+        print(eng.plan())
         eng.set_initial_states(p["psi0"])
         psiT = eng.forward(p["eps"])
         _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
