@@ -478,7 +478,7 @@ template <> struct KrPollLsb<4> {   // slot = two 16-byte words {d0, d1}, {d2, d
 // sgran: 8-byte words between two slots (KR_SLOT_GRANULES: packed; KR_SLOT_GRANULES_LOCAL: one slot per 128-byte line, P <= 64 only)
 template <int LMAX>
 __device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par, const unsigned phase, const int lane, double (&tot)[LMAX],
-                                             const unsigned sgran = KR_SLOT_GRANULES) {
+                                             const unsigned sgran = KR_SLOT_GRANULES, const int seq = -1) {
     static_assert(LMAX == 2 || LMAX == 4, "slot = LMAX doubles in 16-byte words");
     static_assert(LMAX <= 4, "publishing lanes: 4 per replica");
     constexpr int WORDS = KrPollLsb<LMAX>::WORDS;
@@ -500,6 +500,14 @@ __device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par
                     if (l < L) {
                         const unsigned lo = (l & 1) ? g[c][l >> 1].z : g[c][l >> 1].x, hi = (l & 1) ? g[c][l >> 1].w : g[c][l >> 1].y;
                         ok = ok & (((lo & 1u) == phase) | !mine);
+#ifdef KR_GATHER_SEQ
+                        if (seq >= 0 && a.debug && mine && (lo & 1u) == phase && ((lo >> 1) & 0x7fffu) != ((unsigned)seq & 0x7fffu)) {
+                            atomicAdd(a.debug + 12, 1ull);
+                            a.debug[13] = ((unsigned long long)(unsigned)seq << 32) | ((lo >> 1) & 0x7fffu);
+                        }
+#else
+                        (void)seq;
+#endif
                         tot[l] += mine ? __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)) : 0.0;
                     }
                 }
@@ -511,6 +519,16 @@ __device__ __forceinline__ bool kr_poll_pass(const KrSweepArgs &a, const int par
 // Slot value of a partial sum: its bits with the LSB forced to the phase.
 __device__ __forceinline__ unsigned long long kr_slot_bits(const double v, const unsigned phase) {
     return ((unsigned long long)__double_as_longlong(v) & ~1ull) | (unsigned long long)phase;
+}
+// The per-step exchange's slots in a diagnostics build (-DKR_GATHER_SEQ, tools/build_diag.sh): bits 15..1 carry the step index, so that
+// kr_poll_pass can count partial sums that the one-bit validity accepts although they belong to an earlier step (a.debug[12]).
+__device__ __forceinline__ unsigned long long kr_slot_bits_step(const double v, const unsigned phase, const int n) {
+#ifdef KR_GATHER_SEQ   // (n < 0: the positive control of tools/diag_gather_seq.py -- a slot that claims to be four steps old)
+    return (kr_slot_bits(v, phase) & ~0xfffeull) | ((unsigned long long)((unsigned)(n < 0 ? -n - 4 : n) & 0x7fffu) << 1);
+#else
+    (void)n;
+    return kr_slot_bits(v, phase);
+#endif
 }
 
 // EARLY pass of the polling wave (update kernels with window work, one GPU): issued as LDS-DMA in the middle of the window work
@@ -647,7 +665,11 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) if (l == (lane & 3)) v = tot1[l];
             const unsigned long long *dst = a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + (lane >> 2)) * KR_MAIL_RSTRIDE + (size_t)wg * sgran + (lane & 3);
-            const unsigned long long val = kr_slot_bits(v, phase);
+#ifdef KR_GATHER_SEQ
+            const unsigned long long val = kr_slot_bits_step(v, phase, (a.rs_fault && wg == 1 && (n & 15) == 5) ? -n : n);
+#else
+            const unsigned long long val = kr_slot_bits_step(v, phase, n);
+#endif
             if (xlocal) asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(dst), "v"(val) : "memory");   // stays in this XCD's L2
             else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(val) : "memory");
         }
@@ -691,11 +713,11 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
                 if (xlocal) {   // every workgroup of this launch sits on this XCD: one replica, and the store stays in its L2
                     if ((unsigned)(lane >> 2) == kr_xcc_id()) {
                         const unsigned long long *dst = (const unsigned long long *)slot + (lane & 3);
-                        const unsigned long long val = kr_slot_bits(v, phase);
+                        const unsigned long long val = kr_slot_bits_step(v, phase, n);
                         asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(dst), "v"(val) : "memory");
                     }
                 } else {
-                    __hip_atomic_store(slot + (lane & 3), kr_slot_bits(v, phase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(slot + (lane & 3), kr_slot_bits_step(v, phase, n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
 #ifdef KR_ARRIVALS  // diagnostic build: when did every workgroup publish / complete two exchanges in the middle of the sweep
@@ -708,7 +730,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
             const bool early = EARLY && SCHED == 0 && a.world == 1 && P <= 64 * KR_POLL_CHUNKS && P > 1;
             unsigned long long mine_bits[LMAX];
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) mine_bits[l] = kr_slot_bits(tot[l], phase);
+            for (int l = 0; l < LMAX; ++l) mine_bits[l] = kr_slot_bits_step(tot[l], phase, n);
             KrMidPoll<LMAX> mid{a.mail + ((size_t)lpar * KR_MAIL_REPLICAS + kr_xcc_id()) * KR_MAIL_RSTRIDE, spoll, pieces, lane, early, false};
             work(mid);
 #ifdef KR_ARRIVALS
@@ -729,7 +751,7 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 #ifdef KR_ARRIVALS
                 if (arr) arr_m1 = __builtin_amdgcn_s_memtime();
 #endif
-                const bool ok = kr_poll_pass<LMAX>(a, lpar, phase, lane, tot, sgran);
+                const bool ok = kr_poll_pass<LMAX>(a, lpar, phase, lane, tot, sgran, n);
 #ifdef KR_ARRIVALS
                 if (arr) arr_m2 = __builtin_amdgcn_s_memtime();
 #endif
