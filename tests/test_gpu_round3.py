@@ -524,7 +524,8 @@ def test_state_dimension_above_256_with_more_trajectories(oracle_c):
     import test_gpu_parity as tp
     # turns (264: across a rebuild of H(eps); 520 with 8: a multiple of 8 trajectories on TWO groups -- the one-XCD layout of the
     # workgroup ids goes by the groups of a launch, not by the trajectories)
-    for (N, NT, K, L, Kp) in [(300, 4, 20, 1, 24), (264, 34, 9, 2, 16), (520, 2, 3, 1, 4), (400, 3, 70, 2, 72), (516, 2, 8, 1, 8)]:
+    # ((600, 2, 3, 2): NP = 1024 with two controls in two turns -- kr_rowsplit_turns_update<1024, 8, 2>, round 4)
+    for (N, NT, K, L, Kp) in [(300, 4, 20, 1, 24), (264, 34, 9, 2, 16), (520, 2, 3, 1, 4), (400, 3, 70, 2, 72), (516, 2, 8, 1, 8), (600, 2, 3, 2, 4)]:
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=(N == 264))
         assert info["generic_known"] == 0 and info["generic_update"] == 0 and info["K_padded"] == Kp and info["workgroups"] == 256, info
