@@ -12,7 +12,8 @@ The reference ships no golden vectors.  This restatement is therefore pinned
 only by (i) the threshold assertions of the reference's own TLS test
 (/root/reference/test/test_tls_optimization.jl:66-67) and (ii) independent
 mathematics (scipy.linalg.expm, closed-form 2x2 exponentials,
-eigendecomposition).  See DESIGN.md "Oracle".
+eigendecomposition) -- and, recalled from memory, the iteration table that the documentation of the Python
+package `krotov` prints for the same problem family (tests/test_oracle.py).  See DESIGN.md "Oracle".
 
 It restates, in the reference's own order of arithmetic:
 

@@ -137,3 +137,26 @@ def test_handles_of_different_problems_in_turn():
             os.environ.pop("KROTOV_HIP_RS_LMAX1", None)
         else:
             os.environ["KROTOV_HIP_RS_LMAX1"] = old
+
+
+def test_tls_iteration_table_of_the_python_package_docs_on_the_gpu():
+    """The HIP engine on the first example of the Python package `krotov` (tests/test_oracle.py: the table its documentation prints,
+    written down from memory -- [UPSTREAM-RECALLED] --: J_T, sum |delta eps|^2 dt and Delta J_T of iterations 0..5, three digits each)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_oracle as to
+    H0, Hc, tlist, eps, S, lam, psi0, tgt = to.python_krotov_docs_problem()
+    dt = np.diff(tlist)
+    with kr.HipEngine(H0, Hc, tlist, 1) as eng:
+        eng.set_initial_states(psi0)
+        psiT = eng.forward(eps)
+        tau, JT, chiT = wl.chi_and_JT("sm", psiT, tgt)
+        J_T, d2 = [JT], [0.0]
+        for _ in range(5):
+            eps_new, ga, psiT = eng.iteration(eps, chiT, S, lam)
+            tau, JT, chiT = wl.chi_and_JT("sm", psiT, tgt)
+            J_T.append(JT)
+            d2.append(float(np.sum((eps_new - eps) ** 2 * dt)))
+            eps = eps_new
+    to.check_against_python_krotov_docs_table(J_T, d2)
