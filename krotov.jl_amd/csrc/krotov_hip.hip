@@ -76,7 +76,10 @@ struct kr_handle {
     unsigned *present_d = nullptr;
     // device buffers
     double2 *Hpack_fw = nullptr, *Hpack_bw = nullptr;
-    unsigned long long pack_sum[2] = {0ull, 0ull};   // checksums of the host copies of Hpack_fw / Hpack_bw (kr_pack_check)
+    // the operator copies every sweep reads and nothing ever writes after kr_create (kr_pack_check): 0 forward pack, 1 adjoint pack,
+    // 2 dense copies of the matrix-core sweep, 3 / 4 column-major copies (forward / adjoint) of the generic kernels
+    unsigned long long pack_sum[5] = {0ull, 0ull, 0ull, 0ull, 0ull};   // checksums of the host copies
+    size_t const_elems[5] = {0, 0, 0, 0, 0};
     unsigned long long *pack_words_d = nullptr;      // [2] running checksum + block counter of kr_pack_check
     size_t pack_elems = 0;
     double *dt_d = nullptr, *eps_a = nullptr, *eps_b = nullptr, *S_d = nullptr, *lambda_d = nullptr, *gint_d = nullptr;
@@ -1117,12 +1120,13 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         CHK(hipDeviceSynchronize());   // (the host vector is refilled for the adjoint pack: the copy must have left it)
         h->pack_sum[adj] = pack_checksum_host(pack.data(), pack_elems);
     }
+    if (opt_int(h, "PACK_CHECK", 1) != 0) {
+        CHK(dalloc(&h->pack_words_d, 2));
+        CHK(hipMemset(h->pack_words_d, 0, 2 * sizeof(unsigned long long)));
+    }
     if (h->fast_ok) {
         h->pack_elems = pack_elems;
-        if (opt_int(h, "PACK_CHECK", 1) != 0) {
-            CHK(dalloc(&h->pack_words_d, 2));
-            CHK(hipMemset(h->pack_words_d, 0, 2 * sizeof(unsigned long long)));
-        }
+        h->const_elems[0] = h->const_elems[1] = pack_elems;
         if (opt_int(h, "PACK_FAULT", 0) != 0) {   // diagnostics (tests): one mantissa bit of one element of the ADJOINT pack flipped after the upload
             double2 v;
             const size_t at = pack_elems / 3;
@@ -1144,6 +1148,8 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
             }
         CHK(dalloc(&h->Hdense_fw, dense.size()));
         CHK(hipMemcpy(h->Hdense_fw, dense.data(), dense.size() * sizeof(double2), hipMemcpyHostToDevice));
+        h->pack_sum[2] = pack_checksum_host(dense.data(), dense.size());
+        h->const_elems[2] = dense.size();
     }
     h->lam0 = 0.0;
     h->lam_l.assign(L, 0.0);
@@ -1191,6 +1197,9 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
             double2 **dstp = adj ? &h->Hcol_bw : &h->Hcol_fw;
             CHK(dalloc(dstp, col.size()));
             CHK(hipMemcpy(*dstp, col.data(), col.size() * sizeof(double2), hipMemcpyHostToDevice));
+            CHK(hipDeviceSynchronize());   // (the host vector is refilled for the adjoint copy)
+            h->pack_sum[3 + adj] = pack_checksum_host(col.data(), col.size());
+            h->const_elems[3 + adj] = col.size();
         }
         std::vector<int> tile_gen(h->gen_tiles, 0);
         const int per = h->KTILE / h->KTG;   // generic tiles per plan tile
@@ -1700,11 +1709,12 @@ static int launch_update_stepped(kr_handle *h, const double *eps_guess_dev, doub
 }
 
 // one small launch in front of a sweep: the pack it reads still is what kr_create uploaded (kr_pack_check)
-static int pack_precheck(kr_handle *h, bool adjoint) {
-    if (!h->pack_words_d || h->pack_elems == 0) return KR_OK;
-    const int blocks = (int)std::min<size_t>(256, (h->pack_elems + 2047) / 2048);
-    hipLaunchKernelGGL(kr_pack_check, dim3(blocks), dim3(256), 0, h->stream, adjoint ? h->Hpack_bw : h->Hpack_fw, h->pack_elems,
-                       h->pack_sum[adjoint ? 1 : 0], h->pack_words_d, adjoint ? 1 : 0, h->status_d);
+static int pack_precheck(kr_handle *h, int which) {   // which: 0 forward pack, 1 adjoint pack, 2 dense (matrix cores), 3 / 4 column-major fw / adjoint
+    const double2 *bufs[5] = {h->Hpack_fw, h->Hpack_bw, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw};
+    const size_t n = h->const_elems[which];
+    if (!h->pack_words_d || n == 0 || !bufs[which]) return KR_OK;
+    const int blocks = (int)std::min<size_t>(256, (n + 2047) / 2048);
+    hipLaunchKernelGGL(kr_pack_check, dim3(blocks), dim3(256), 0, h->stream, bufs[which], n, h->pack_sum[which], h->pack_words_d, which, h->status_d);
     HIPCHK(h, hipGetLastError());
     return KR_OK;
 }
@@ -1712,7 +1722,7 @@ static int pack_precheck(kr_handle *h, bool adjoint) {
 static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool backward, const double2 *init, double2 *store, double2 *fin) {
     KrSweepArgs a;
     base_args(h, a);
-    if (!h->gen_known) { const int prc = pack_precheck(h, backward); if (prc) return prc; }
+    { const int prc = pack_precheck(h, h->gen_known ? (backward ? 4 : 3) : (backward ? 1 : 0)); if (prc) return prc; }
     a.Hpack = backward ? h->Hpack_bw : h->Hpack_fw;
     a.eps = eps_dev;
     a.init = init; a.store = store; a.fin = fin;
@@ -1810,7 +1820,9 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
 
 static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_new_dev, int calib_steps = 0) {
     if (h->gen_update) {
-        int rc0 = ev_mark(h, 2, false);
+        int rc0 = pack_precheck(h, 3);
+        if (rc0) return rc0;
+        rc0 = ev_mark(h, 2, false);
         if (rc0) return rc0;
         rc0 = launch_update_stepped(h, eps_guess_dev, eps_new_dev);
         if (rc0) return rc0;
@@ -1821,7 +1833,11 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     KrSweepArgs a;
     base_args(h, a);
     if (calib_steps) { a.NT = calib_steps; a.world = 1; a.rank = 0; }  // calibration: first steps only, this GPU alone
-    else { const int prc = pack_precheck(h, false); if (prc) return prc; }
+    else {
+        int prc = pack_precheck(h, 0);
+        if (prc == KR_OK && h->mfma_sweep) prc = pack_precheck(h, 2);   // the matrix-core sweep takes its A operands from the dense copies
+        if (prc) return prc;
+    }
     a.Hpack = h->Hpack_fw;
     a.eps = eps_guess_dev;
     a.init = h->psi0_d; a.store = h->store_fw ? h->Phi_d : nullptr; a.fin = h->psiT_d;
@@ -1951,7 +1967,7 @@ static int check_status(kr_handle *h) {
                         st[2], h->method == KR_PROP_CHEBY ? "Chebyshev" : "Newton");
         if (st[1] == 7)
             return fail(h, KR_ERR_INTERNAL, "the %s generator pack on the device no longer matches the operators kr_create uploaded (checksum mismatch in front of a sweep): device memory was corrupted; results of this call are invalid -- create a new handle",
-                        st[2] ? "adjoint (backward-sweep)" : "forward");
+                        st[2] == 0 ? "forward" : st[2] == 1 ? "adjoint (backward-sweep)" : st[2] == 2 ? "dense (matrix-core)" : st[2] == 3 ? "column-major forward" : "column-major adjoint");
         if (st[1] == 6)
             return fail(h, KR_ERR_INTERNAL, "row-split sweep: the %d workgroups that share trajectory tile %u ended the sweep with different copies of its state vector (an all-gather element was lost or accepted stale); results of this call are invalid",
                         h->R, st[2]);
