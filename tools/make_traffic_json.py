@@ -8,7 +8,7 @@ import os
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 shapes = {"C2": (16, 500, 32), "C3": (64, 1000, 256), "C4": (64, 1000, 1024), "C5": (256, 2000, 64)}
 dominant = {"C2": "kr_sweep_update", "C3": "kr_sweep_update", "C4": "kr_mf_update", "C5": "kr_rowsplit_pair_sweep"}

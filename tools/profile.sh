@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): kernel-trace stats, then PMC passes, of the bench command.
 # Outputs under gpurun_out/prof_<tag>/ ; copy the summaries you want judged into profiles/.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 CONFIG=${2:-C3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
