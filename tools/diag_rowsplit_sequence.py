@@ -33,11 +33,18 @@ def main():
     print("references done", flush=True)
     worst = {}
     nbad = 0
+    loud = {}
     for r in range(reps):
         for ci, p in enumerate(cases):
             for mode in ["0", "1"]:
                 os.environ["KROTOV_HIP_RS_LMAX1"] = mode
-                psiT, (eps_new, ga, psiT1), plan = iterate(p)
+                try:
+                    psiT, (eps_new, ga, psiT1), plan = iterate(p)
+                except kr.KrotovHipError as exc:     # loud failures (bounded spins under a loaded GPU, integrity checks) are counted, not hidden
+                    loud[exc.code] = loud.get(exc.code, 0) + 1
+                    if loud[exc.code] <= 3:
+                        print("rep %d case %d mode %s: error %d: %s" % (r, ci, mode, exc.code, str(exc)[:200]), flush=True)
+                    continue
                 e_fw = np.max(np.abs(psiT - refs[ci]["psiT"]))
                 e_eps = np.max(np.abs(eps_new - refs[ci]["eps_new"])) / np.max(np.abs(refs[ci]["eps_new"]))
                 key = (ci, mode)
@@ -46,7 +53,8 @@ def main():
                     nbad += 1
                     d = (eps_new - refs[ci]["eps_new"])[0]
                     print("rep %d case %d mode %s: fw %.2e eps %.2e | d[:6] %s d[-6:] %s | %s" % (r, ci, mode, e_fw, e_eps, d[:6], d[-6:], plan), flush=True)
-    print("worst relative pulse error per (case, mode):", {k: "%.1e" % v for k, v in worst.items()}, "bad runs:", nbad, flush=True)
+    print("worst relative pulse error per (case, mode):", {k: "%.1e" % v for k, v in worst.items()}, "silently wrong runs:", nbad,
+          "loud failures by status code:", loud, flush=True)
 
 
 if __name__ == "__main__":
