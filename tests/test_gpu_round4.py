@@ -160,3 +160,31 @@ def test_tls_iteration_table_of_the_python_package_docs_on_the_gpu():
             d2.append(float(np.sum((eps_new - eps) ** 2 * dt)))
             eps = eps_new
     to.check_against_python_krotov_docs_table(J_T, d2)
+
+
+@pytest.mark.parametrize("shape,functional", [((12, 60, 6, 2), "sm"), ((40, 40, 24, 1), "re"), ((100, 30, 6, 2), "ss")])
+def test_thirty_iterations_track_the_oracle(shape, functional):
+    """A whole optimization, not one iteration: thirty Krotov iterations on the HIP engine and on the NumPy oracle, each fed with ITS
+    OWN pulses and states (errors would compound), must stay together -- J_T to 1e-10 absolute, pulses to 1e-9 relative -- and J_T
+    must fall monotonically (Krotov's guarantee, /root/reference/src/optimize.jl:190-228)."""
+    import krotov_oracle as o
+    N, NT, K, L = shape
+    p = wl.dense_problem(N, NT, K, L, 9100 + N, 0.05, 2.0)
+    eps_o = p["eps"].copy()
+    psiT_o, _ = o.forward(p["H0"], p["Hc"], p["tlist"], eps_o, p["psi0"], store=False)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        eng.set_initial_states(p["psi0"])
+        eps = p["eps"].copy()
+        psiT = eng.forward(eps)
+        last = None
+        for it in range(30):
+            _, JT, chiT = wl.chi_and_JT(functional, psiT, p["tgt"])
+            _, JT_o, chiT_o = wl.chi_and_JT(functional, psiT_o, p["tgt"])
+            assert abs(JT - JT_o) < 1e-10, (it, JT, JT_o)
+            assert last is None or JT <= last + 1e-13, (it, JT, last)
+            last = JT
+            eps, ga, psiT = eng.iteration(eps, chiT, p["S"], p["lam"])
+            eps_o, ga_o, psiT_o, _, _ = o.iteration(p["H0"], p["Hc"], p["tlist"], eps_o, p["S"], p["lam"], p["psi0"], chiT_o)
+            assert np.max(np.abs(eps - eps_o)) < 1e-9 * np.max(np.abs(eps_o)), (it, np.max(np.abs(eps - eps_o)))
+        J0 = wl.chi_and_JT(functional, o.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False)[0], p["tgt"])[1]
+        assert last < J0 - 1e-5, (last, J0)     # (and it did move: thirty real updates)
