@@ -1296,7 +1296,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     rc = calibrate_exchange(h);
     if (rc != KR_OK) return bail(rc);
     {   // kr_plan_description(): which kernels carry this problem, and why if not the persistent ones
-        char buf[640];
+        char buf[800];
         const char *upd = h->gen_update ? "generic per-step kernels (kr_gen_partial/reduce/form/apply)"
                         : h->rowsplit ? (h->rs_pair ? "kr_rowsplit_pair_sweep (two interleaved trajectories per group)"
                                          : h->rs_turns > 0 ? "kr_rowsplit_turns_update (the groups of workgroups carry several trajectories in turn)" : "kr_rowsplit_sweep")
@@ -1305,9 +1305,11 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         const char *known = h->gen_known ? "kr_gen_known" : h->rowsplit ? (h->rs_batch > 0 ? "kr_rowsplit_sweep in batches of launches" : "kr_rowsplit_sweep") : h->precomp ? "kr_expm + kr_sweep_apply" : "kr_sweep_known";
         static const char *const exn[] = {"auto", "mailbox", "rccl", "callback"};
         snprintf(buf, sizeof buf, "N=%d (padded %d) NT=%d K=%d (padded %d) L=%d G=%d rank %d/%d on device %d: update sweep = %s, %d workgroups x %d "
-                 "trajectories, sets per workgroup %d, one-XCD placement %d, R=%d, HERM=%d, economized=%d, poll_delay=%d; known-pulse sweeps = %s; exchange = %s; spin bound %.0f ms%s%s",
+                 "trajectories, sets per workgroup %d, one-XCD placement %d, R=%d, HERM=%d, economized=%d, poll_delay=%d; known-pulse sweeps = %s; exchange = %s; spin bound %.0f ms; "
+                 "integrity checks: operator-copy checksums %s, group coherence words %s%s%s",
                  h->cfg.N, h->NP, h->cfg.NT, h->cfg.K, h->Kp, h->cfg.L, h->G, h->cfg.rank, h->cfg.world, h->device, upd, h->P, h->KTILE, h->rs_turns > 0 ? h->rs_turns : h->sets,
                  h->wg_stride > 1 ? 1 : 0, h->rowsplit ? h->R : 1, h->herm ? 1 : 0, (h->econ || h->econ_gen) ? 1 : 0, h->poll_delay, known, exn[h->exchange & 3], (double)h->spin_ticks / 1e5,
+                 h->pack_words_d ? "on" : "off", (h->rowsplit && h->R > 1) ? "on" : "n/a",
                  h->plan_note.empty() ? "" : "; note: ", h->plan_note.c_str());
         h->plan_text = buf;
     }
