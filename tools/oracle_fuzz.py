@@ -1,0 +1,128 @@
+"""Developer tool: random problems DIRECTLY against the oracle (tools/plan_fuzz.py compares the plans with the generic kernels, which
+tests/test_gpu_generic.py pins to the oracle; this one skips the middle man).  Random N, K, L, N_T, Hermitian or dissipative drifts,
+one or two generators with random assignment, absent control derivatives (control_derivs === nothing, optimize.jl:344), non-uniform
+grids, all three functionals, random update shapes and lambda_a per control: one forward sweep + two chained iterations on the HIP
+engine and on the NumPy oracle (exact step propagators), states to 1e-11, pulses to 1e-10 relative, the UPDATE itself (delta eps, which
+the pulses' rounding hides) to 1e-8 of its largest value, the running integral to 1e-9.
+   python tools/oracle_fuzz.py [COUNT=150] [SEED=1]        (ORACLE_FUZZ_NMAX=130: state dimensions up to 130 only)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import krotov_jl_amd as kr  # noqa: E402
+from krotov_jl_amd import workloads as wl  # noqa: E402
+import krotov_oracle as o  # noqa: E402
+
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for it in range(count):
+    NS = [1, 2, 3, 5, 8, 9, 16, 17, 24, 32, 33, 48, 64, 65, 80, 100, 128, 130, 160, 200, 256, 257, 300]
+    if os.environ.get("ORACLE_FUZZ_NMAX"):   # (the oracle's exact propagators cost seconds per shape at N >= 200: the test suite stays below)
+        NS = [n for n in NS if n <= int(os.environ["ORACLE_FUZZ_NMAX"])]
+    N = int(rng.choice(NS))
+    kmax = 300 if N <= 64 else (64 if N <= 130 else (24 if N <= 256 else 6))
+    K = int(rng.integers(1, kmax + 1))
+    L = int(rng.choice([1, 1, 2, 2, 3, 4]))
+    NT = int(rng.choice([1, 2, 5, 9, 34]))
+    if N > 256 and L > 2:
+        L = 2
+    p = wl.dense_problem(N, NT, K, L, 7000 + it, float(rng.choice([0.02, 0.05, 0.2])), 2.0)
+    tag = ""
+    kw = {}
+    if rng.random() < 0.3:
+        p["H0"] = p["H0"] - 1j * float(rng.choice([0.003, 0.05, 0.3])) * np.diag(rng.uniform(0, 1, N)) + (0.02 * rng.normal(size=(N, N)) if rng.random() < 0.5 else 0.0)
+        tag += " nonherm"
+    G = 1
+    tg = np.zeros(K, np.int32)
+    H0s, Hcs = p["H0"][None], p["Hc"][None]
+    if rng.random() < 0.25 and K >= 2 and N <= 256:
+        G = 2
+        H0s = np.stack([p["H0"], 0.8 * p["H0"]])
+        Hcs = np.stack([p["Hc"], 1.2 * p["Hc"]])
+        tg = rng.integers(0, 2, K).astype(np.int32)
+        kw["traj_generator"] = tg
+        tag += " G=2"
+    pres = np.ones((G, L), np.uint8)
+    if L >= 2 and rng.random() < 0.3:
+        pres[int(rng.integers(0, G)), int(rng.integers(0, L))] = 0
+        kw["hc_present"] = pres
+        tag += " mask"
+    if rng.random() < 0.3 and NT > 1:
+        p["tlist"] = np.concatenate([[0.0], np.cumsum(np.diff(p["tlist"]) * rng.uniform(0.5, 1.5, NT))])
+        tag += " grid"
+    p["S"] = p["S"] * rng.uniform(0.3, 1.0, (L, 1))
+    p["lam"] = rng.uniform(0.5, 8.0, L)
+    fname = str(rng.choice(["sm", "ss", "re"]))
+    t0 = time.time()
+    try:
+        # oracle: per-trajectory generators by groups (the oracle's routines take one generator)
+        def o_forward(eps):
+            out = np.empty((K, N), complex)
+            for g in range(G):
+                m = tg == g
+                if m.any():
+                    out[m] = o.forward(H0s[g], Hcs[g], p["tlist"], eps, p["psi0"][m], store=False)[0]
+            return out
+
+        def o_iteration(eps, chiT):
+            X = np.empty((NT + 1, K, N), complex)
+            for g in range(G):
+                m = tg == g
+                if m.any():
+                    X[:, m] = o.backward(H0s[g], Hcs[g], p["tlist"], eps, chiT[m])
+            psi = p["psi0"].copy()
+            eps_new = eps.copy()
+            ga = np.zeros(L)
+            for n in range(NT):
+                dt = p["tlist"][n + 1] - p["tlist"][n]
+                for l in range(L):
+                    du = 0.0
+                    for k in range(K):
+                        if pres[tg[k], l]:
+                            du += np.vdot(X[n, k], Hcs[tg[k], l] @ psi[k]).imag
+                    alpha = p["S"][l, n] / p["lam"][l]
+                    eps_new[l, n] = eps[l, n] + alpha * du
+                    ga[l] += alpha * du * du * dt
+                for g in range(G):
+                    m = tg == g
+                    if m.any():
+                        psi[m] = psi[m] @ o.step_propagator(H0s[g], Hcs[g], eps_new[:, n], dt).T
+            return eps_new, ga, psi
+
+        Harg = (H0s[0], Hcs[0]) if G == 1 else (H0s, Hcs)
+        with kr.HipEngine(Harg[0], Harg[1], p["tlist"], K, **kw) as eng:
+            eng.set_initial_states(p["psi0"])
+            psiT = eng.forward(p["eps"])
+            psiT_o = o_forward(p["eps"])
+            d0 = np.max(np.abs(psiT - psiT_o))
+            eps, eps_o = p["eps"], p["eps"]
+            d1 = d2 = d3 = d4 = 0.0
+            for _ in range(2):
+                _, _, chiT = wl.chi_and_JT(fname, psiT_o, p["tgt"])
+                guess = eps_o
+                eps, ga, psiT = eng.iteration(guess, chiT, p["S"], p["lam"])
+                eps_o, ga_o, psiT_o = o_iteration(guess, chiT)
+                d1 = max(d1, np.max(np.abs(eps - eps_o)) / max(np.max(np.abs(eps_o)), 1e-300))
+                # the UPDATE itself (the pulses hide it: delta eps is a small correction of eps): relative to the largest update
+                # (an update below 1e-9 of the pulse is rounding noise -- N = 1: Im<chi|H|psi> of a scalar system -- and is not compared)
+                if np.max(np.abs(eps_o - guess)) > 1e-9 * np.max(np.abs(guess)):
+                    d4 = max(d4, np.max(np.abs((eps - guess) - (eps_o - guess))) / np.max(np.abs(eps_o - guess)))
+                d2 = max(d2, np.max(np.abs(psiT - psiT_o)))
+                d3 = max(d3, np.max(np.abs(ga - ga_o)) / max(np.max(np.abs(ga_o)), 1e-300) if np.max(np.abs(ga_o)) > 1e-20 else 0.0)
+            info = eng.info()
+        ok = d0 < 1e-11 and d1 < 1e-10 and d2 < 1e-10 and d3 < 1e-9 and d4 < 1e-8
+        print("%-4s N=%4d K=%4d L=%d NT=%2d J_T_%s NP=%4d R=%3d wg=%3d genK=%d genU=%d  dpsi %.1e deps %.1e dupd %.1e dpsi' %.1e dga %.1e  %.1fs%s" % (
+            "ok" if ok else "BAD", N, K, L, NT, fname, info["NP"], info["rowsplit_R"], info["workgroups"], info["generic_known"], info["generic_update"],
+            d0, d1, d4, d2, d3, time.time() - t0, tag), flush=True)
+        bad += 0 if ok else 1
+    except Exception as exc:  # noqa: BLE001
+        bad += 1
+        print("FAIL N=%4d K=%4d L=%d NT=%2d%s: %s" % (N, K, L, NT, tag, str(exc)[:200]), flush=True)
+print("oracle_fuzz: %d problem(s) in %d shapes" % (bad, count))
+sys.exit(1 if bad else 0)
