@@ -17,8 +17,9 @@
 #define KR_SPIN_DEFAULT_TICKS 400000000ull  // 4 s of s_memrealtime (100 MHz): default bound of every in-kernel spin
                                             // (kr_config.spin_timeout_ms overrides it per handle: KrSweepArgs::spin_ticks)
 
-// status words (device): [0] abort/timeout flag, [1] where, [2] step, [3] spare
-#define KR_STATUS_WORDS 4
+// status words (device): [0] abort/timeout flag, [1] where, [2] step, [3] spare, [4..5] s_memrealtime at the start of the last update
+// sweep of a handle with peers (world > 1: who was late when a bounded spin between GPUs gives up), [6..7] spare
+#define KR_STATUS_WORDS 8
 
 struct KrSweepArgs {
     // generator slices, thread-major: Hpack[g][m][jj][tid_in_team] (double2), g = generator, m = 0..L

@@ -24,6 +24,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <chrono>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -101,6 +102,13 @@ struct kr_handle {
     double *skw_d = nullptr;    // [G][1 + KR_LMAX_CAP] 2-norm bounds of the anti-Hermitian parts (pair mode with a generator that is not Hermitian), or nullptr
     int poll_delay = -1;  // exchange schedule of the update sweep (KrSweepArgs::poll_delay), set by calibrate_exchange
     unsigned long long *peer_xmail[8]{};
+    // host timeline of the last update sweep (ms since the library was loaded) and the device clock at which its kernel started:
+    // a timeout between shards of one handle is reported with every shard's line (group_run)
+    double tl_launch0 = 0, tl_launch1 = 0, tl_wait0 = 0, tl_wait1 = 0;
+    unsigned long long tl_kernel_start = 0;
+    int mail_kind = 0, xmail_kind = 0;   // 0 ordinary hipMalloc, 1 uncached, 2 fine-grained (special_alloc: returned to the pool, not freed)
+    size_t xmail_bytes = 0;
+    unsigned last_epoch_base = 0;   // tag base of the last update launch (the timeout report prints the tags it expected)
     bool peers_connected = false;
     bool peers_in_process = false;   // peer mailboxes are plain pointers of sibling shards (device list), not IPC mappings
     unsigned *status_d = nullptr;
@@ -155,8 +163,12 @@ static int opt_int(const kr_handle *h, const char *name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
+static double now_ms() {
+    static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 static int fail(kr_handle *h, int code, const char *fmt, ...) {
-    char buf[1024];
+    char buf[3072];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
@@ -243,7 +255,7 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
 static const char *const kr_option_names[] = {
     "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
     "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "PACK_CHECK", "PACK_FAULT", "POLL_DELAY", "PRECOMP", "ROWSPLIT",
-    "RS512", "RS_BATCH", "RS_FAULT", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "STAMPS", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY"};
+    "RS512", "RS_BATCH", "RS_FAULT", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "SHARD_SKEW_MS", "STAMPS", "UC_POOL", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY", "ZERO_KERNEL", "ZERO_SYNC"};
 static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
     out.clear();
     if (!text) return true;
@@ -417,6 +429,13 @@ __global__ __launch_bounds__(256) void kr_pack_check(const double2 *p, size_t n,
             atomicExch(words + 1, 0ull);
         }
     }
+}
+
+// Zeroing in front of a launch (mailboxes with one-bit validity, the running integrals) as an ordinary kernel on the handle's stream:
+// KROTOV_HIP_ZERO_KERNEL=1 (default: hipMemsetAsync), KROTOV_HIP_ZERO_SYNC=1 waits for it on the host -- diagnostics that ruled the
+// zeroing out as the source of the partial sums lost in round 4 ("device lists").
+__global__ __launch_bounds__(256) void kr_zero_words(unsigned long long *p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0ull;
 }
 
 // After a single-mode row-split sweep (kr_rowsplit_sweep): the R workgroups of every trajectory posted a checksum of the state
@@ -888,15 +907,17 @@ extern "C" int kr_abi_version(void) { return KR_ABI_VERSION; }
 
 extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+static void special_release(kr_handle *h, void *p, size_t bytes, int kind);
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->pack_words_d, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
-                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->mail_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d, h->skw_d,
+                    h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d, h->skw_d,
                     h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected && !h->peers_in_process)
         for (int r = 0; r < h->cfg.world; ++r)
             if (r != h->cfg.rank && h->peer_xmail[r]) (void)hipIpcCloseMemHandle(h->peer_xmail[r]);
-    if (h->xmail_d) (void)hipFree(h->xmail_d);
+    if (h->mail_d) { if (h->mail_kind) special_release(h, h->mail_d, h->mail_words * sizeof(unsigned long long), h->mail_kind); else (void)hipFree(h->mail_d); }
+    if (h->xmail_d) { if (h->xmail_kind) special_release(h, h->xmail_d, h->xmail_bytes, h->xmail_kind); else (void)hipFree(h->xmail_d); }
     if (h->du_host) (void)hipHostFree(h->du_host);
     if (h->rccl_comm && kr_rccl()) (void)kr_rccl()->CommDestroy(h->rccl_comm);
     for (auto &pool : h->ev) for (auto &e : pool) if (e) (void)hipEventDestroy(e);
@@ -922,13 +943,42 @@ static hipError_t dalloc(T **p, size_t count) {
 // with sc1: same-box A/B of the update sweep, C3 (P = 256): 7.17-7.25 -> 6.85-6.89 us per step, C4: 18.4 -> 17.9;
 // fine-grained memory: no gain (7.17-7.25); with few workgroups ordinary memory is slightly faster (C2, P = 8: 4.16
 // against 4.22).  KROTOV_HIP_MAIL_MEM = 0 (hipMalloc) / 1 (uncached) / 2 (fine-grained) overrides the choice.
+// Uncached / fine-grained blocks are never handed back to the runtime while the library is loaded: a handle returns its block to a
+// process-wide pool (per device, kind and size) and the next handle that asks for the same takes it from there (KROTOV_HIP_UC_POOL=0:
+// hipFree as before).  See DESIGN.md, "device lists": [round 4] with blocks of both kinds allocated and freed in turn by the handles
+// of one process, partial sums published into an ORDINARY mailbox went missing.
+struct KrSpecialBlock { void *p; int device, kind; size_t bytes; };
+static std::mutex g_special_mtx;
+static std::vector<KrSpecialBlock> g_special_free;
+static hipError_t special_alloc(kr_handle *h, void **p, size_t bytes, int kind /* 1 uncached, 2 fine-grained */) {
+    if (opt_int(h, "UC_POOL", 1) != 0) {
+        std::lock_guard<std::mutex> g(g_special_mtx);
+        for (size_t i = 0; i < g_special_free.size(); ++i)
+            if (g_special_free[i].device == h->device && g_special_free[i].kind == kind && g_special_free[i].bytes == bytes) {
+                *p = g_special_free[i].p;
+                g_special_free.erase(g_special_free.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipExtMallocWithFlags(p, bytes, kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+}
+static void special_release(kr_handle *h, void *p, size_t bytes, int kind) {
+    if (!p) return;
+    if (opt_int(h, "UC_POOL", 1) != 0) {
+        try {
+            std::lock_guard<std::mutex> g(g_special_mtx);
+            g_special_free.push_back({p, h->device, kind, bytes});
+            return;
+        } catch (...) {}
+    }
+    (void)hipFree(p);
+}
 static hipError_t alloc_mailbox(kr_handle *h, unsigned long long **p, size_t words, int pollers) {
     const int mm = opt_int(h, "MAIL_MEM", pollers >= 64 ? 1 : 0);
-    (void)h;
+    h->mail_kind = 0;
     if (mm != 0) {
-        const hipError_t e = hipExtMallocWithFlags((void **)p, std::max<size_t>(words, 1) * sizeof(unsigned long long),
-                                                   mm == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
-        if (e == hipSuccess) return e;
+        const hipError_t e = special_alloc(h, (void **)p, std::max<size_t>(words, 1) * sizeof(unsigned long long), mm == 1 ? 1 : 2);
+        if (e == hipSuccess) { h->mail_kind = mm == 1 ? 1 : 2; return e; }
         (void)hipGetLastError();  // not available on this device/driver: fall back to ordinary memory
     }
     return dalloc(p, words);
@@ -1281,11 +1331,15 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         // inter-GPU mailbox: written by peers over xGMI, polled by this GPU's kernels -> uncached/fine-grained
         const size_t xwords = (size_t)2 * 8 * 2 * KR_LMAX_CAP + 2 * 8 * 4;   // update-sweep slots + tau slots (KR_XMAIL_TAU_OFF)
         // preference: uncached, then fine-grained, then plain device memory (peers always use system-scope atomics)
-        if (hipExtMallocWithFlags((void **)&h->xmail_d, xwords * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) {
+        h->xmail_bytes = xwords * sizeof(unsigned long long);
+        h->xmail_kind = 1;
+        if (special_alloc(h, (void **)&h->xmail_d, h->xmail_bytes, 1) != hipSuccess) {
             (void)hipGetLastError();
-            if (hipExtMallocWithFlags((void **)&h->xmail_d, xwords * sizeof(unsigned long long), hipDeviceMallocFinegrained) != hipSuccess) {
+            h->xmail_kind = 2;
+            if (special_alloc(h, (void **)&h->xmail_d, h->xmail_bytes, 2) != hipSuccess) {
                 (void)hipGetLastError();
-                CHK(hipMalloc((void **)&h->xmail_d, xwords * sizeof(unsigned long long)));
+                h->xmail_kind = 0;
+                CHK(hipMalloc((void **)&h->xmail_d, h->xmail_bytes));
             }
         }
         CHK(hipMemset(h->xmail_d, 0, xwords * sizeof(unsigned long long)));
@@ -1481,13 +1535,21 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
 
 // vector-mailbox tags of the row-split kernels: (launch id mod 256) << 24 | gather counter; the mailbox is cleared
 // whenever the launch id wraps, and a launch may use at most 2^24 gathers (N_T * rounds per step)
+static int zero_async(kr_handle *h, void *p, size_t words) {
+    if (opt_int(h, "ZERO_KERNEL", 0) == 0) { HIPCHK(h, hipMemsetAsync(p, 0, words * sizeof(unsigned long long), h->stream)); return KR_OK; }
+    const int blocks = (int)std::min<size_t>(512, (words + 255) / 256);
+    hipLaunchKernelGGL(kr_zero_words, dim3(std::max(blocks, 1)), dim3(256), 0, h->stream, (unsigned long long *)p, words);
+    HIPCHK(h, hipGetLastError());
+    if (opt_int(h, "ZERO_SYNC", 0) != 0) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KR_OK;
+}
 static int rowsplit_prelaunch(kr_handle *h, KrSweepArgs &a) {
     if ((long long)h->cfg.NT * (KR_MAX_ORDER + 2) * 4 >= (1ll << 24))
         return fail(h, KR_ERR_UNSUPPORTED, "row-split kernels: N_T = %d too large for the mailbox tag space (set KROTOV_HIP_ROWSPLIT=0)", h->cfg.NT);
     h->launch_id = (h->launch_id + 1) & 0xffu;
     if (h->launch_id == 0) h->launch_id = 1;
     // the all-gather validates its elements with one bit per double whose phase starts at 1 in every launch: start from zeros
-    HIPCHK(h, hipMemsetAsync(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long), h->stream));
+    { const int zrc = zero_async(h, h->gmail_d, h->gmail_words); if (zrc) return zrc; }
     a.epoch_base2 = h->launch_id << 24;
     return KR_OK;   // (the status words are sticky: only check_status clears them)
 }
@@ -1674,7 +1736,7 @@ static int launch_update_stepped(kr_handle *h, const double *eps_guess_dev, doub
     }
     HIPCHK(h, hipMemcpyAsync(h->psiT_d, h->psi0_d, slab * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
     if (h->store_fw) HIPCHK(h, hipMemcpyAsync(h->Phi_d, h->psi0_d, slab * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->gint_d, 0, (size_t)L * sizeof(double), h->stream));
+    { const int zrc = zero_async(h, h->gint_d, (size_t)L); if (zrc) return zrc; }
     const int form_grid = (int)(((size_t)h->G * N * N + 255) / 256);
     // One rank (the sum stays on the device), L <= 32: TWO launches per time step instead of four -- the pulse update sums the
     // tiles' partials itself, the forward step adds the partial sums of the next step (kr_device_generic.h; round 3).  The
@@ -1846,6 +1908,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     a.X = h->X_d; a.alpha = h->S_d; a.eps_new = eps_new_dev; a.g_a_int = h->gint_d;
     a.dir = +1;
     a.epoch_base = h->epoch_base;
+    h->last_epoch_base = h->epoch_base;
     // next launch: first tag = last tag + 3 (odd step: buffer parity keeps alternating); 32-bit wrap-around is
     // harmless because every slot is rewritten every second event and tags are only compared for equality
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
@@ -1858,9 +1921,10 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     }
     // the mailbox inside the GPU validates its slots with one bit per double whose phase starts at 1 in every launch
     // (kr_exchange): start from zeros
-    HIPCHK(h, hipMemsetAsync(h->mail_d, 0, h->mail_words * sizeof(unsigned long long), h->stream));
+    { const int zrc = zero_async(h, h->mail_d, h->mail_words); if (zrc) return zrc; }
     int rc = ev_mark(h, 2, false);
     if (rc) return rc;
+    h->tl_launch0 = now_ms();
     if (h->rowsplit) {
         rc = rowsplit_prelaunch(h, a);
         if (rc) return rc;
@@ -1879,6 +1943,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
             HIPCHK(h, h->launch(h->LMAXv, h->KT, kind, h->P * a.wg_stride, h->stream, &a));
         }
     }
+    h->tl_launch1 = now_ms();
     return ev_mark(h, 2, true);
 }
 
@@ -1950,16 +2015,19 @@ static int calibrate_exchange(kr_handle *h) {
     // calibration tags from the intra-GPU mailbox (calibration runs with world = 1: xmail was never written).
     h->epoch_base = epoch_saved;
     if (rc == KR_OK) {
-        HIPCHK(h, hipMemsetAsync(h->mail_d, 0, h->mail_words * sizeof(unsigned long long), h->stream));
+        { const int zrc = zero_async(h, h->mail_d, h->mail_words); if (zrc) return zrc; }
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return rc;
 }
 
 static int check_status(kr_handle *h) {
-    unsigned st[KR_STATUS_WORDS] = {0, 0, 0, 0};
+    unsigned st[KR_STATUS_WORDS] = {};
+    h->tl_wait0 = now_ms();
     HIPCHK(h, hipMemcpyAsync(st, h->status_d, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->tl_wait1 = now_ms();
+    h->tl_kernel_start = ((unsigned long long)st[5] << 32) | st[4];
     if (st[0] != 0) {
         // sticky until read (launches never clear it, so a failure inside a chain of *_dev calls is not lost)
         HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
@@ -1977,8 +2045,52 @@ static int check_status(kr_handle *h) {
                          : st[1] == 2 ? "inter-GPU exchange of the update sweep"
                          : st[1] == 3 ? "row-split all-gather (the R workgroups of a trajectory)"
                                       : "inter-workgroup exchange of the update sweep";
-        return fail(h, KR_ERR_TIMEOUT, "sweep aborted: bounded spin of the %s gave up at %s %u (status code %u); results of this call are invalid",
-                    what, st[1] == 3 ? "gather" : "step", st[2], st[1]);
+        std::string seen;
+        if (st[1] == 2 && h->xmail_d && h->cfg.world > 1) {   // what did arrive: the tags in this GPU's mailbox, both buffers, one row per rank
+            const int W = h->cfg.world, LM = h->LMAXv;
+            std::vector<unsigned long long> xm((size_t)2 * W * 2 * LM, 0ull);
+            if (hipMemcpyAsync(xm.data(), h->xmail_d, xm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess) {
+                char b[96];
+                snprintf(b, sizeof b, "; expected tag %u in buffer %u, mailbox holds", h->last_epoch_base + st[2] + 1u, (h->last_epoch_base + st[2] + 1u) & 1u);
+                seen = b;
+                for (int par = 0; par < 2; ++par)
+                    for (int r = 0; r < W; ++r) {
+                        snprintf(b, sizeof b, " [buf %d rank %d:", par, r);
+                        seen += b;
+                        for (int w = 0; w < 2 * std::min(h->cfg.L, LM); ++w) { snprintf(b, sizeof b, " %u", (unsigned)(xm[((size_t)par * W + r) * 2 * LM + w] >> 32)); seen += b; }
+                        seen += "]";
+                    }
+            }
+        }
+        if ((st[1] == 2 || st[1] == 1) && h->mail_d && !h->rowsplit && h->wg_stride == 1) {
+            // ... and inside this GPU: how many of the P workgroups' partial sums of that step each replica of the mailbox holds
+            const int LM = h->LMAXv, lpar = (int)(st[2] & 1u);
+            const unsigned phase = ((st[2] >> 1) & 1u) ^ 1u;
+            std::vector<unsigned long long> mb((size_t)KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE, 0ull);
+            if (hipMemcpyAsync(mb.data(), h->mail_d + (size_t)lpar * KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE, mb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                hipStreamSynchronize(h->stream) == hipSuccess) {
+                seen += "; partial sums of that step in the mailbox replicas:";
+                char b[48];
+                for (int r = 0; r < KR_MAIL_REPLICAS; ++r) {
+                    int cnt = 0;
+                    for (int q = 0; q < h->P; ++q) cnt += ((unsigned)(mb[(size_t)r * KR_MAIL_RSTRIDE + (size_t)q * LM] & 1ull) == phase) ? 1 : 0;
+                    snprintf(b, sizeof b, " %d", cnt);
+                    seen += b;
+                    if (cnt < h->P) {   // what the replica holds instead: its first words, and how far the damage reaches
+                        char w[400];
+                        const unsigned long long *rp = &mb[(size_t)r * KR_MAIL_RSTRIDE];
+                        size_t nz = 0, last = 0;
+                        for (size_t q = 0; q < KR_MAIL_RSTRIDE; ++q) if (rp[q]) { ++nz; last = q; }
+                        snprintf(w, sizeof w, " {%016llx %016llx %016llx %016llx %016llx %016llx %016llx %016llx; nonzero words %zu, last at %zu}", rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7], nz, last);
+                        seen += w;
+                    }
+                }
+                snprintf(b, sizeof b, " of %d", h->P);
+                seen += b;
+            }
+        }
+        return fail(h, KR_ERR_TIMEOUT, "sweep aborted: bounded spin of the %s gave up at %s %u (status code %u); results of this call are invalid%s",
+                    what, st[1] == 3 ? "gather" : "step", st[2], st[1], seen.c_str());
     }
     return KR_OK;
 }
@@ -2315,7 +2427,12 @@ static int group_run(kr_handle *g, F f) {
     std::vector<int> rcs(P, KR_OK);
     std::vector<std::thread> th;
     // a shard's body never lets an exception leave its thread (that would be std::terminate inside a ccall)
-    auto body = [&rcs, &f, g](int i) { rcs[i] = kr_guard(g->subs[i], "shard thread", [&] { return f(g->subs[i], i); }); };
+    // (KROTOV_HIP_SHARD_SKEW_MS, a test facility: shard i starts i x that many ms late -- the shards of other processes / hosts are never in step either)
+    const int skew = opt_int(g->subs[0], "SHARD_SKEW_MS", 0);
+    auto body = [&rcs, &f, g, skew](int i) {
+        if (skew > 0 && i > 0) std::this_thread::sleep_for(std::chrono::milliseconds((long)skew * i));
+        rcs[i] = kr_guard(g->subs[i], "shard thread", [&] { return f(g->subs[i], i); });
+    };
     try {
         for (int i = 1; i < P; ++i) th.emplace_back(body, i);
     } catch (...) {   // std::system_error: could not start a thread -- the shards already running are joined before the error leaves
@@ -2325,7 +2442,20 @@ static int group_run(kr_handle *g, F f) {
     body(0);
     for (auto &t : th) t.join();
     for (int i = 0; i < P; ++i)
-        if (rcs[i] != KR_OK) return fail(g, rcs[i], "shard %d of %d (device %d): %s", i, P, g->subs[i]->device, g->subs[i]->err.c_str());
+        if (rcs[i] != KR_OK) {
+            std::string tl;
+            if (rcs[i] == KR_ERR_TIMEOUT) {   // who was late: every shard's host timeline of its last update sweep + the device clock at its kernel's start
+                char b[256];
+                tl = "; timelines [ms]:";
+                for (int j = 0; j < P; ++j) {
+                    const kr_handle *s = g->subs[j];
+                    snprintf(b, sizeof b, " shard %d launch %.2f..%.2f wait %.2f..%.2f kernel start tick %llu (rc %d);", j, s->tl_launch0, s->tl_launch1, s->tl_wait0, s->tl_wait1, s->tl_kernel_start, rcs[j]);
+                    tl += b;
+                    if (j != i && rcs[j] != KR_OK) tl += " shard " + std::to_string(j) + " reports: " + s->err + ";";
+                }
+            }
+            return fail(g, rcs[i], "shard %d of %d (device %d): %s%s", i, P, g->subs[i]->device, g->subs[i]->err.c_str(), tl.c_str());
+        }
     return KR_OK;
 }
 static inline bool is_group(const kr_handle *h) { return h && !h->subs.empty(); }

@@ -5,6 +5,8 @@ grids, all three functionals, random update shapes and lambda_a per control: one
 engine and on the NumPy oracle (exact step propagators), states to 1e-11, pulses to 1e-10 relative, the UPDATE itself (delta eps, which
 the pulses' rounding hides) to 1e-8 of its largest value, the running integral to 1e-9.
    python tools/oracle_fuzz.py [COUNT=150] [SEED=1]        (ORACLE_FUZZ_NMAX=130: state dimensions up to 130 only;
+    ORACLE_FUZZ_DEVLIST=1: every handle drives two shards on the one GPU (kr_config.devices = {0, 0});
+    ORACLE_FUZZ_DEVCHAIN=1: the two iterations also as one device-resident chain (kr_iteration_functional_dev);
     ORACLE_FUZZ_HARD=1: half the shapes with ||H dt|| up to ~6 -- sub-stepping --, many with lambda_a / 50 -- large updates)"""
 import os
 import sys
@@ -75,6 +77,8 @@ for it in range(count):
     fname = str(rng.choice(["sm", "ss", "re"]))
     if os.environ.get("ORACLE_FUZZ_ONLY") and it != int(os.environ["ORACLE_FUZZ_ONLY"]):   # (replay ONE shape of a run: the draws above are consumed all the same)
         continue
+    if it < int(os.environ.get("ORACLE_FUZZ_FROM", "0")):   # (skip the first shapes of a run, draws consumed)
+        continue
     t0 = time.time()
     try:
         # oracle: per-trajectory generators by groups (the oracle's routines take one generator)
@@ -112,6 +116,11 @@ for it in range(count):
             return eps_new, ga, psi
 
         Harg = (H0s[0], Hcs[0]) if G == 1 else (H0s, Hcs)
+        if os.environ.get("ORACLE_FUZZ_DEVLIST") and K >= 2:
+            # ONE handle with a device list that names the GPU twice: two shards (library threads, peer-pointer mailboxes) share it --
+            # the inter-GPU exchange of the update sweep on random shapes
+            kw["devices"] = [0, 0]
+            tag += " devlist"
         with kr.HipEngine(Harg[0], Harg[1], p["tlist"], K, **kw) as eng:
             eng.set_initial_states(p["psi0"])
             psiT = eng.forward(p["eps"])
@@ -132,13 +141,32 @@ for it in range(count):
                 d2 = max(d2, np.max(np.abs(psiT - psiT_o)))
                 d3 = max(d3, np.max(np.abs(ga - ga_o)) / max(np.max(np.abs(ga_o)), 1e-300) if np.max(np.abs(ga_o)) > 1e-20 else 0.0)
             info = eng.info()
-        ok = d0 < 1e-11 and d1 < 1e-10 and d2 < 1e-10 and d3 < 1e-9 and d4 < 1e-8
+        d5 = 0.0
+        if os.environ.get("ORACLE_FUZZ_DEVCHAIN"):
+            # the same two iterations as ONE device-resident chain (tau, J_T and chi(T) formed on the device, pulses ping-pong in device
+            # memory: kr_forward_dev / kr_iteration_functional_dev): must land on the oracle's chain as well
+            import torch
+            with kr.HipEngine(Harg[0], Harg[1], p["tlist"], K, **kw) as e2:
+                e2.set_initial_states(p["psi0"])
+                e2.set_target_states(p["tgt"])
+                e2.set_update_params(p["S"], p["lam"])
+                ea = torch.from_numpy(np.ascontiguousarray(p["eps"])).cuda()
+                eb = torch.empty_like(ea)
+                torch.cuda.synchronize()
+                e2.forward_dev(ea.data_ptr())
+                for _ in range(2):
+                    e2.iteration_functional_dev({"sm": 0, "ss": 1, "re": 2}[fname], ea.data_ptr(), eb.data_ptr())
+                    ea, eb = eb, ea
+                e2.synchronize()
+                d5 = max(np.max(np.abs(ea.cpu().numpy() - eps_o)) / max(np.max(np.abs(eps_o)), 1e-300), np.max(np.abs(e2.final_states() - psiT_o)) * 0.1)
+            tag += " devchain %.1e" % d5
+        ok = d0 < 1e-11 and d1 < 1e-10 and d2 < 1e-10 and d3 < 1e-9 and d4 < 1e-8 and d5 < 1e-10
         print("%-4s N=%4d K=%4d L=%d NT=%2d J_T_%s NP=%4d R=%3d wg=%3d genK=%d genU=%d  dpsi %.1e deps %.1e dupd %.1e dpsi' %.1e dga %.1e  %.1fs%s" % (
             "ok" if ok else "BAD", N, K, L, NT, fname, info["NP"], info["rowsplit_R"], info["workgroups"], info["generic_known"], info["generic_update"],
             d0, d1, d4, d2, d3, time.time() - t0, tag), flush=True)
         bad += 0 if ok else 1
     except Exception as exc:  # noqa: BLE001
         bad += 1
-        print("FAIL N=%4d K=%4d L=%d NT=%2d%s: %s" % (N, K, L, NT, tag, str(exc)[:200]), flush=True)
+        print("FAIL N=%4d K=%4d L=%d NT=%2d%s: %s" % (N, K, L, NT, tag, str(exc)[:1500]), flush=True)
 print("oracle_fuzz: %d problem(s) in %d shapes" % (bad, count))
 sys.exit(1 if bad else 0)
