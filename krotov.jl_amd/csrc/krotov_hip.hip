@@ -106,6 +106,7 @@ struct kr_handle {
     // a timeout between shards of one handle is reported with every shard's line (group_run)
     double tl_launch0 = 0, tl_launch1 = 0, tl_wait0 = 0, tl_wait1 = 0;
     unsigned long long tl_kernel_start = 0;
+    bool peers_cached = false;   // peer mailboxes come from the process-wide cache of IPC mappings: never closed by this handle
     int mail_kind = 0, xmail_kind = 0;   // 0 ordinary hipMalloc, 1 uncached, 2 fine-grained (special_alloc: returned to the pool, not freed)
     size_t xmail_bytes = 0;
     unsigned last_epoch_base = 0;   // tag base of the last update launch (the timeout report prints the tags it expected)
@@ -913,7 +914,7 @@ static void free_all(kr_handle *h) {
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d, h->skw_d,
                     h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (h->peers_connected && !h->peers_in_process)
+    if (h->peers_connected && !h->peers_in_process && !h->peers_cached)   // (cached mappings stay open: ipc_open)
         for (int r = 0; r < h->cfg.world; ++r)
             if (r != h->cfg.rank && h->peer_xmail[r]) (void)hipIpcCloseMemHandle(h->peer_xmail[r]);
     if (h->mail_d) { if (h->mail_kind) special_release(h, h->mail_d, h->mail_words * sizeof(unsigned long long), h->mail_kind); else (void)hipFree(h->mail_d); }
@@ -2398,6 +2399,21 @@ static int one_ipc_export(kr_handle *h, void *handle_out) {
     return KR_OK;
 }
 
+// A peer's mailbox is an uncached block of another process; unmapping it here (hipIpcCloseMemHandle) is the same event as freeing an
+// uncached block of our own (special_alloc): mappings are opened once per process and exporter block and kept (the exporter pools its
+// blocks, so a later handle of the same peer presents the same IPC handle again and gets the mapping that is already there).
+static std::mutex g_ipc_mtx;
+static std::vector<std::tuple<int, hipIpcMemHandle_t, void *>> g_ipc_open;   // (device, handle, mapping)
+static hipError_t ipc_open(kr_handle *h, const hipIpcMemHandle_t &mh, void **p) {
+    if (opt_int(h, "UC_POOL", 1) == 0) { h->peers_cached = false; return hipIpcOpenMemHandle(p, mh, hipIpcMemLazyEnablePeerAccess); }
+    std::lock_guard<std::mutex> g(g_ipc_mtx);
+    h->peers_cached = true;
+    for (auto &e : g_ipc_open)
+        if (std::get<0>(e) == h->device && memcmp(&std::get<1>(e), &mh, sizeof mh) == 0) { *p = std::get<2>(e); return hipSuccess; }
+    const hipError_t rc = hipIpcOpenMemHandle(p, mh, hipIpcMemLazyEnablePeerAccess);
+    if (rc == hipSuccess) g_ipc_open.emplace_back(h->device, mh, *p);
+    return rc;
+}
 static int one_ipc_connect(kr_handle *h, const void *all_handles) {
     if (!h || !all_handles) return h ? fail(h, KR_ERR_INVALID, "kr_ipc_connect: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
@@ -2408,7 +2424,7 @@ static int one_ipc_connect(kr_handle *h, const void *all_handles) {
         hipIpcMemHandle_t mh;
         memcpy(&mh, (const char *)all_handles + (size_t)r * sizeof mh, sizeof mh);
         void *p = nullptr;
-        HIPCHK(h, hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess));
+        HIPCHK(h, ipc_open(h, mh, &p));
         h->peer_xmail[r] = (unsigned long long *)p;
     }
     h->peers_connected = true;

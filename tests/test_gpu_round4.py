@@ -1,4 +1,5 @@
 """GPU tests of round 4: the rigorous norm bounds behind the step polynomials."""
+import os
 import numpy as np
 import pytest
 
@@ -188,3 +189,21 @@ def test_thirty_iterations_track_the_oracle(shape, functional):
             assert np.max(np.abs(eps - eps_o)) < 1e-9 * np.max(np.abs(eps_o)), (it, np.max(np.abs(eps - eps_o)))
         J0 = wl.chi_and_JT(functional, o.forward(p["H0"], p["Hc"], p["tlist"], p["eps"], p["psi0"], store=False)[0], p["tgt"])[1]
         assert last < J0 - 1e-5, (last, J0)     # (and it did move: thirty real updates)
+
+
+def test_recycled_uncached_blocks_microbenchmark(tmp_path):
+    """tools/ubench/uc_recycle.hip is the library's allocation pattern without the library: handles whose mailbox is an uncached or an
+    ordinary block, everything freed, addresses recycled.  On ROCm 7.2 / MI355X a block that reuses the address range of a FREED
+    uncached block loses stores (ordinary block) or hides them from some XCDs (uncached block) -- mode 9, ~460 of 2000 exchanges,
+    one host thread, nothing concurrent.  The library therefore never frees such blocks (special_alloc, krotov_hip.hip); mode 8 is that
+    policy and must be clean.  Mode 9 is reported, not asserted (a fixed runtime makes it pass)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "uc_recycle")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ubench", "uc_recycle.hip")
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-o", exe, src, "-lpthread"], check=True, timeout=600)
+    pooled = subprocess.run([exe, "150", "8"], capture_output=True, text=True, timeout=300)
+    assert pooled.returncode == 0, pooled.stdout[-2000:]
+    freed = subprocess.run([exe, "150", "9", "1"], capture_output=True, text=True, timeout=300)
+    print("uc_recycle, blocks freed (informational):", freed.stdout.strip().splitlines()[-1])
