@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 #include <atomic>
@@ -46,6 +47,14 @@ __global__ __launch_bounds__(256) void exchange(unsigned long long *mail, int P,
 }
 
 static std::atomic<int> g_bad{0}, g_handles{0};
+// UC_KIND=uncached (default) | finegrained | host: what the "special" blocks are (host: pinned host memory, hipHostMalloc / hipHostFree --
+// the exchange then runs on ordinary mailboxes only and the special block is just allocated, touched by a memset and freed)
+static int g_kind = 0;
+static void special_malloc(void **p, size_t bytes) {
+    if (g_kind == 2) CK(hipHostMalloc(p, bytes, hipHostMallocDefault));
+    else CK(hipExtMallocWithFlags(p, bytes, g_kind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
+}
+static void special_free(void *p) { if (g_kind == 2) CK(hipHostFree(p)); else CK(hipFree(p)); }
 static std::vector<void *> g_uc_pool[2];
 
 static void worker(int tid, int handles, int mode, unsigned seed) {
@@ -120,7 +129,7 @@ static void groups(int handles, bool pool, bool in_turn = false) {
         rs = rs * 1664525u + 1013904223u;
         const bool single = ((rs >> 5) % 4 == 0);            // some handles have one shard only
         const int P = ((rs >> 20) % 3 == 0) ? 64 : 2 + (int)((rs >> 8) % 60);
-        const bool uc = P >= 64;
+        const bool uc = P >= 64 && g_kind != 2;   // (pinned host memory: only the small block is special)
         const int S = single ? 1 : 2;
         hipStream_t st[2]; unsigned long long *mail[2]; void *xm[2]; unsigned *res[2]; void *nb[2][3];
         for (int s = 0; s < S; ++s) {
@@ -128,12 +137,12 @@ static void groups(int handles, bool pool, bool in_turn = false) {
             for (int i = 0; i < 3; ++i) CK(hipMalloc(&nb[s][i], 65536 + 4096 * ((rs >> (4 * i + s)) & 15)));
             if (uc) {
                 if (pool && !big_pool.empty()) { mail[s] = (unsigned long long *)big_pool.back(); big_pool.pop_back(); }
-                else CK(hipExtMallocWithFlags((void **)&mail[s], WORDS * 8, hipDeviceMallocUncached));
+                else special_malloc((void **)&mail[s], WORDS * 8);
             } else CK(hipMalloc((void **)&mail[s], WORDS * 8));
             CK(hipMemset(mail[s], 0, WORDS * 8));
             CK(hipMalloc((void **)&res[s], 64 * 4));
             if (pool && !small_pool.empty()) { xm[s] = small_pool.back(); small_pool.pop_back(); }
-            else CK(hipExtMallocWithFlags(&xm[s], 2560, hipDeviceMallocUncached));
+            else special_malloc(&xm[s], 2560);
             CK(hipMemset(xm[s], 0, 2560));
             CK(hipDeviceSynchronize());
         }
@@ -159,8 +168,8 @@ static void groups(int handles, bool pool, bool in_turn = false) {
         for (int s = 0; s < S; ++s) {
             for (int i = 0; i < 3; ++i) CK(hipFree(nb[s][i]));
             CK(hipFree(res[s]));
-            if (uc && pool) big_pool.push_back(mail[s]); else CK(hipFree(mail[s]));
-            if (pool) small_pool.push_back(xm[s]); else CK(hipFree(xm[s]));
+            if (uc && pool) big_pool.push_back(mail[s]); else if (uc) special_free(mail[s]); else CK(hipFree(mail[s]));
+            if (pool) small_pool.push_back(xm[s]); else special_free(xm[s]);
             CK(hipStreamDestroy(st[s]));
         }
     }
@@ -168,6 +177,7 @@ static void groups(int handles, bool pool, bool in_turn = false) {
 
 int main(int argc, char **argv) {
     const int handles = argc > 1 ? atoi(argv[1]) : 400, mode = argc > 2 ? atoi(argv[2]) : 0, threads = argc > 3 ? atoi(argv[3]) : 2;
+    if (getenv("UC_KIND")) g_kind = !strcmp(getenv("UC_KIND"), "finegrained") ? 1 : !strcmp(getenv("UC_KIND"), "host") ? 2 : 0;
     CK(hipSetDevice(0));
     if (mode == 7 || mode == 8 || mode == 9) groups(handles, mode == 8, mode == 9);
     else if (mode == 4 || mode == 5) {   // phase 1 on one thread (4: kinds mixed and freed, 5: ordinary only), phase 2: two threads, ORDINARY blocks only
