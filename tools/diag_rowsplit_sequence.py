@@ -34,6 +34,21 @@ def main():
     worst = {}
     nbad = 0
     loud = {}
+    # DIAG_POISON=n: first n device-list handles of mixed shapes (two shards on the one GPU: uncached mailboxes between the shards, big-grid
+    # uncached and small-grid ordinary mailboxes), created, used once and destroyed -- what tests/test_gpu_device_list.py leaves behind in
+    # the test process before tests/test_gpu_parity.py runs (with KROTOV_HIP_UC_POOL=0 their uncached blocks are freed: DESIGN.md)
+    rng = np.random.default_rng(11)
+    for i in range(int(os.environ.get("DIAG_POISON", "0"))):
+        N = int(rng.choice([9, 16, 33, 48, 64])); K = int(rng.choice([8, 40, 107, 130, 256])); L = int(rng.choice([1, 2]))
+        q = wl.dense_problem(N, 5, K, L, 900 + i, 0.05, 2.0)
+        try:
+            with kr.HipEngine(q["H0"], q["Hc"], q["tlist"], K, devices=[0, 0], spin_timeout_ms=300) as eng:
+                eng.set_initial_states(q["psi0"])
+                psiT = eng.forward(q["eps"])
+                _, _, chiT = wl.chi_and_JT("ss", psiT, q["tgt"])
+                eng.iteration(q["eps"], chiT, q["S"], q["lam"])
+        except kr.KrotovHipError as exc:
+            print("poison handle %d (N=%d K=%d): error %d" % (i, N, K, exc.code), flush=True)
     for r in range(reps):
         for ci, p in enumerate(cases):
             for mode in ["0", "1"]:

@@ -12,6 +12,7 @@
 //   mode 4: 60 handles of mixed kinds on ONE thread (everything freed), then two threads with ordinary blocks only; mode 5: the control
 //           (phase 1 with ordinary blocks only)
 //   mode 7: the library's device list (see groups() below), everything freed; mode 8: uncached blocks kept and reused;
+//   mode 10: 960 ordinary blocks of random sizes allocated and freed first, then mode 8 in turn (uncached blocks allocated LATE in a process)
 //   mode 9: as 7, but the two shards' exchanges run one after the other from the main thread (no second thread, nothing concurrent)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -179,7 +180,17 @@ int main(int argc, char **argv) {
     const int handles = argc > 1 ? atoi(argv[1]) : 400, mode = argc > 2 ? atoi(argv[2]) : 0, threads = argc > 3 ? atoi(argv[3]) : 2;
     if (getenv("UC_KIND")) g_kind = !strcmp(getenv("UC_KIND"), "finegrained") ? 1 : !strcmp(getenv("UC_KIND"), "host") ? 2 : 0;
     CK(hipSetDevice(0));
-    if (mode == 7 || mode == 8 || mode == 9) groups(handles, mode == 8, mode == 9);
+    if (mode == 10) {   // ordinary blocks of many sizes allocated and freed first, THEN the pooled pattern: uncached blocks that are allocated late
+        std::vector<void *> v;
+        unsigned rs = 5u;
+        for (int round = 0; round < 40; ++round) {
+            for (int i = 0; i < 24; ++i) { rs = rs * 1664525u + 1013904223u; void *q; CK(hipMalloc(&q, 4096 + (size_t)(rs >> 8) % (3u << 20))); CK(hipMemset(q, 1, 4096)); v.push_back(q); }
+            CK(hipDeviceSynchronize());
+            for (void *q : v) CK(hipFree(q));
+            v.clear();
+        }
+        groups(handles, true, true);
+    } else if (mode == 7 || mode == 8 || mode == 9) groups(handles, mode == 8, mode == 9);
     else if (mode == 4 || mode == 5) {   // phase 1 on one thread (4: kinds mixed and freed, 5: ordinary only), phase 2: two threads, ORDINARY blocks only
         worker(0, 60, mode == 4 ? 6 : 1, 4242u);
         printf("phase 1 done: %d exchanges with lost or unseen words\n", g_bad.load());
