@@ -17,9 +17,10 @@
 #define KR_SPIN_DEFAULT_TICKS 400000000ull  // 4 s of s_memrealtime (100 MHz): default bound of every in-kernel spin
                                             // (kr_config.spin_timeout_ms overrides it per handle: KrSweepArgs::spin_ticks)
 
-// status words (device): [0] abort/timeout flag, [1] where, [2] step, [3] spare, [4..5] s_memrealtime at the start of the last update
-// sweep of a handle with peers (world > 1: who was late when a bounded spin between GPUs gives up), [6..7] spare
-#define KR_STATUS_WORDS 8
+// status words (device): [0] abort/timeout flag, [1] where, [2] step, [3] spare
+// (a device clock stamp of the sending wave at the first exchange was tried in round 4 for the timeout report of device lists: it cost the
+//  C3 update sweep 3 % -- 5.17 -> 5.32 us per step, same-box A/B -- although the branch is never taken on one GPU; removed)
+#define KR_STATUS_WORDS 4
 
 struct KrSweepArgs {
     // generator slices, thread-major: Hpack[g][m][jj][tid_in_team] (double2), g = generator, m = 0..L

@@ -680,10 +680,6 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
         //     every rank's xmail (slot = this rank).  Its stores cross xGMI; a wave that polls after storing waits for
         //     their acknowledgements with its first pass (vmcnt counts loads and stores together), so the polling wave 0
         //     never stores to a peer and this wave never waits (asm stores, not counted by the compiler either).
-        if (n == 0 && lane == 0) {   // when did this GPU reach the sweep's first exchange (status words 4..5: the timeout report of a device list)
-            const unsigned long long t = kr_realtime();
-            a.status[4] = (unsigned)t; a.status[5] = (unsigned)(t >> 32);
-        }
         if (SCHED == 1) for (int w = 0; w < a.poll_delay; ++w) __builtin_amdgcn_s_sleep(2);
         double tf[LMAX];
         const int W = a.world;

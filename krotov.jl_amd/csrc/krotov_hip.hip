@@ -102,10 +102,9 @@ struct kr_handle {
     double *skw_d = nullptr;    // [G][1 + KR_LMAX_CAP] 2-norm bounds of the anti-Hermitian parts (pair mode with a generator that is not Hermitian), or nullptr
     int poll_delay = -1;  // exchange schedule of the update sweep (KrSweepArgs::poll_delay), set by calibrate_exchange
     unsigned long long *peer_xmail[8]{};
-    // host timeline of the last update sweep (ms since the library was loaded) and the device clock at which its kernel started:
+    // host timeline of the last update sweep (ms since the library was loaded):
     // a timeout between shards of one handle is reported with every shard's line (group_run)
     double tl_launch0 = 0, tl_launch1 = 0, tl_wait0 = 0, tl_wait1 = 0;
-    unsigned long long tl_kernel_start = 0;
     bool peers_cached = false;   // peer mailboxes come from the process-wide cache of IPC mappings: never closed by this handle
     int mail_kind = 0, xmail_kind = 0;   // 0 ordinary hipMalloc, 1 uncached, 2 fine-grained (special_alloc: returned to the pool, not freed)
     size_t xmail_bytes = 0;
@@ -2028,7 +2027,6 @@ static int check_status(kr_handle *h) {
     HIPCHK(h, hipMemcpyAsync(st, h->status_d, sizeof st, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->tl_wait1 = now_ms();
-    h->tl_kernel_start = ((unsigned long long)st[5] << 32) | st[4];
     if (st[0] != 0) {
         // sticky until read (launches never clear it, so a failure inside a chain of *_dev calls is not lost)
         HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->stream));
@@ -2460,12 +2458,12 @@ static int group_run(kr_handle *g, F f) {
     for (int i = 0; i < P; ++i)
         if (rcs[i] != KR_OK) {
             std::string tl;
-            if (rcs[i] == KR_ERR_TIMEOUT) {   // who was late: every shard's host timeline of its last update sweep + the device clock at its kernel's start
+            if (rcs[i] == KR_ERR_TIMEOUT) {   // who was late: every shard's host timeline of its last update sweep
                 char b[256];
                 tl = "; timelines [ms]:";
                 for (int j = 0; j < P; ++j) {
                     const kr_handle *s = g->subs[j];
-                    snprintf(b, sizeof b, " shard %d launch %.2f..%.2f wait %.2f..%.2f kernel start tick %llu (rc %d);", j, s->tl_launch0, s->tl_launch1, s->tl_wait0, s->tl_wait1, s->tl_kernel_start, rcs[j]);
+                    snprintf(b, sizeof b, " shard %d launch %.2f..%.2f wait %.2f..%.2f (rc %d);", j, s->tl_launch0, s->tl_launch1, s->tl_wait0, s->tl_wait1, rcs[j]);
                     tl += b;
                     if (j != i && rcs[j] != KR_OK) tl += " shard " + std::to_string(j) + " reports: " + s->err + ";";
                 }
