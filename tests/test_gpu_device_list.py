@@ -121,3 +121,30 @@ def test_max_workgroups_is_honoured(oracle_c):
         eng.set_initial_states(p["psi0"])
         eng.forward(p["eps"])
         assert _rel(eng.iteration(p["eps"], chiT, p["S"], p["lam"])[0], eps_o) < 1e-10
+
+
+def test_a_late_shard_times_out_with_a_report_and_the_handle_recovers(oracle_c):
+    """Round 4: the shards of a device list wait for each other inside their kernels, bounded by kr_config.spin_timeout_ms.  A shard
+    that starts 400 ms late (KROTOV_HIP_SHARD_SKEW_MS, a test facility) against a bound of 100 ms: KR_ERR_TIMEOUT, and the message
+    says who was late -- every shard's host timeline, the tags its mailbox between GPUs holds against the tag it expected (the early
+    shard holds its own partial sums and not the peer's), and how many partial sums each replica of the local mailbox holds (all of
+    them: the loss was between the GPUs).  The same problem on a fresh handle without the skew is exact afterwards."""
+    p = wl.dense_problem(12, 6, 20, 2, 541, 0.1, 1.0)
+    K = 20
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, devices=[0, 0], spin_timeout_ms=100, options={"SHARD_SKEW_MS": 400}) as eng:
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])                  # known-pulse sweeps do not wait for anybody
+        _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])
+        with pytest.raises(kr.KrotovHipError) as ei:
+            eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        msg = str(ei.value)
+        assert ei.value.code == capi.KR_ERR_TIMEOUT
+        assert "shard 0 of 2" in msg and "gave up at step 0" in msg and "timelines [ms]" in msg and "shard 1 launch" in msg
+        assert "expected tag 1 in buffer 1" in msg and "[buf 1 rank 0: 1 1 1 1] [buf 1 rank 1: 0 0 0 0]" in msg, msg
+        assert "partial sums of that step in the mailbox replicas: " + " ".join([str(eng.info()["workgroups"])] * 8) in msg, msg
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, devices=[0, 0]) as eng:
+        eng.set_initial_states(p["psi0"])
+        eng.forward(p["eps"])
+        eps_new = eng.iteration(p["eps"], chiT, p["S"], p["lam"])[0]
+    eps_o = oracle_c.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT)[0]
+    assert _rel(eps_new, eps_o) < 1e-10
