@@ -32,3 +32,12 @@ def test_device_list_handles_in_a_process_that_has_seen_every_kind_of_handle():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "oracle_fuzz.py"), "42", "8"], capture_output=True, text=True,
                        timeout=900, env=e, cwd=ROOT)
     assert r.returncode == 0 and "oracle_fuzz: 0 problem(s) in 42 shapes" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_two_processes_many_handles_in_turn_over_ipc_mailboxes():
+    """tools/ipc_fuzz.py: the N > 1 path as bench.py --gpus N runs it (one process per rank, mailboxes mapped through IPC), two ranks
+    on the one GPU, 40 random problems IN TURN per process -- pooled mailboxes are exported again and the peers' cached IPC mappings are
+    reused (round 4) --, every pulse identical on both ranks and within 1e-10 of the C oracle on the whole ensemble."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ipc_fuzz.py"), "40", "3"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "ipc_fuzz: 0 problem(s) in 40 shapes" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
