@@ -117,7 +117,10 @@ typedef struct kr_config {
     int32_t exchange;              /* kr_exchange                                              */
     int32_t prop_method;           /* kr_prop_method                                           */
     int32_t max_workgroups;        /* cap on co-resident persistent workgroups of this handle (0 = derive from the
-                                      device's occupancy; several handles sharing one GPU must split its CUs)   */
+                                      device's occupancy; several handles sharing one GPU must split its CUs -- XCD
+                                      by XCD: a launch's workgroups are dealt out to the 8 XCDs in turn, so the caps
+                                      of handles that run at the same time must satisfy sum ceil(cap / 8) <= 32, the
+                                      CUs of one XCD; a device list that repeats an ordinal does that by itself)   */
     int32_t n_devices;             /* > 1: ONE handle drives n_devices GPUs from this process (trajectories block-
                                       partitioned over them; rank/world must be 0/1); 0 or 1: `device` alone     */
     int32_t devices[8];            /* HIP device ordinals of the n_devices GPUs (the same ordinal may repeat)     */

@@ -2517,7 +2517,14 @@ static int group_create(const kr_config *cfg, kr_handle **out) {
         if (share[i] > 1) {   // shards that share a GPU split its CUs (their persistent kernels must all be resident at once)
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { fail(g, KR_ERR_HIP, "hipGetDeviceProperties failed"); return bail(KR_ERR_HIP); }
-            const int cap = std::max(1, prop.multiProcessorCount / share[i]);
+            // ... XCD by XCD: the dispatcher deals a launch's workgroups out to the 8 XCDs in turn, so a kernel of P workgroups
+            // needs ceil(P / 8) CUs on some XCDs (one persistent workgroup per CU in the big variants), and the shards' kernels all start
+            // with the same XCD: three shards of 82 workgroups (85 = 256 / 3 allowed) put 33 on the 32 CUs of XCD 0 and 1 -- found by
+            // the fuzzer (ORACLE_FUZZ_DEVLIST=3, round 4) as timeouts of the first exchange.  Whole rounds of 8 only.
+            // Three kernels that fill the chip to 240 of 256 CUs still missed each other in 1-5 of 150 fuzzed shapes (more hardware
+            // queues -- GPU_MAX_HW_QUEUES=8 -- 1 of 150; 64 workgroups per shard: 0 of 150; two shards of 128 never, 962 shapes): three
+            // shards take a quarter of the chip each.
+            const int cap = std::max(1, (prop.multiProcessorCount / 8 / (share[i] > 2 ? share[i] + 1 : share[i])) * 8);
             c.max_workgroups = (cfg->max_workgroups > 0) ? std::min(cfg->max_workgroups, cap) : cap;
         }
         const int rc = one_create(&c, &g->subs[i]);

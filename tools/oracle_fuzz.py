@@ -5,7 +5,7 @@ grids, all three functionals, random update shapes and lambda_a per control: one
 engine and on the NumPy oracle (exact step propagators), states to 1e-11, pulses to 1e-10 relative, the UPDATE itself (delta eps, which
 the pulses' rounding hides) to 1e-8 of its largest value, the running integral to 1e-9.
    python tools/oracle_fuzz.py [COUNT=150] [SEED=1]        (ORACLE_FUZZ_NMAX=130: state dimensions up to 130 only;
-    ORACLE_FUZZ_DEVLIST=1: every handle drives two shards on the one GPU (kr_config.devices = {0, 0});
+    ORACLE_FUZZ_DEVLIST=1: every handle drives two shards on the one GPU (kr_config.devices = {0, 0}), = 3: three;
     ORACLE_FUZZ_DEVCHAIN=1: the two iterations also as one device-resident chain (kr_iteration_functional_dev);
     ORACLE_FUZZ_HARD=1: half the shapes with ||H dt|| up to ~6 -- sub-stepping --, many with lambda_a / 50 -- large updates)"""
 import os
@@ -119,8 +119,8 @@ for it in range(count):
         if os.environ.get("ORACLE_FUZZ_DEVLIST") and K >= 2:
             # ONE handle with a device list that names the GPU twice: two shards (library threads, peer-pointer mailboxes) share it --
             # the inter-GPU exchange of the update sweep on random shapes
-            kw["devices"] = [0, 0]
-            tag += " devlist"
+            kw["devices"] = [0, 0, 0] if (os.environ["ORACLE_FUZZ_DEVLIST"] == "3" and K >= 3) else [0, 0]   # (= 3: three shards)
+            tag += " devlist%d" % len(kw["devices"])
         with kr.HipEngine(Harg[0], Harg[1], p["tlist"], K, **kw) as eng:
             eng.set_initial_states(p["psi0"])
             psiT = eng.forward(p["eps"])
