@@ -41,3 +41,12 @@ def test_two_processes_many_handles_in_turn_over_ipc_mailboxes():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ipc_fuzz.py"), "40", "3"], capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "ipc_fuzz: 0 problem(s) in 40 shapes" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_random_call_sequences_on_one_handle_against_the_oracle():
+    """tools/api_fuzz.py: 5-10 calls in random order per handle -- forward, backward, update sweeps (several on one backward sweep),
+    iterations, other initial states in between, reads of both storages, final states, running integrals -- each checked against the C
+    oracle: what one call leaves behind for the next."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "api_fuzz.py"), "40", "5"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "api_fuzz: 0 problem(s) in 40 shapes" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
