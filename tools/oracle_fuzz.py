@@ -7,6 +7,7 @@ the pulses' rounding hides) to 1e-8 of its largest value, the running integral t
    python tools/oracle_fuzz.py [COUNT=150] [SEED=1]        (ORACLE_FUZZ_NMAX=130: state dimensions up to 130 only;
     ORACLE_FUZZ_DEVLIST=1: every handle drives two shards on the one GPU (kr_config.devices = {0, 0}), = 3: three;
     ORACLE_FUZZ_DEVCHAIN=1: the two iterations also as one device-resident chain (kr_iteration_functional_dev);
+    ORACLE_FUZZ_METHODS=1: most shapes with prop_method = Chebyshev / Newton or the generic Taylor kernels forced;
     ORACLE_FUZZ_HARD=1: half the shapes with ||H dt|| up to ~6 -- sub-stepping --, many with lambda_a / 50 -- large updates)"""
 import os
 import sys
@@ -116,6 +117,15 @@ for it in range(count):
             return eps_new, ga, psi
 
         Harg = (H0s[0], Hcs[0]) if G == 1 else (H0s, Hcs)
+        if os.environ.get("ORACLE_FUZZ_METHODS") and rng.random() < 0.7:
+            # kr_config.prop_method (the reference's prop_method): Chebyshev (Hermitian generators only), Newton at Leja points, or the
+            # generic multi-pass kernels with Taylor steps -- all three on the generic kernels
+            m = str(rng.choice(["cheby", "newton", "generic"])) if "nonherm" not in tag else str(rng.choice(["newton", "generic"]))
+            if m == "generic":
+                kw["options"] = {"GENERIC": 1}
+            else:
+                kw["prop_method"] = kr._capi.KR_PROP_CHEBY if m == "cheby" else kr._capi.KR_PROP_NEWTON
+            tag += " " + m
         if os.environ.get("ORACLE_FUZZ_DEVLIST") and K >= 2:
             # ONE handle with a device list that names the GPU twice: two shards (library threads, peer-pointer mailboxes) share it --
             # the inter-GPU exchange of the update sweep on random shapes
