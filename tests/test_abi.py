@@ -95,3 +95,16 @@ def test_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle_c" not in src and "krotov_oracle" not in src, f
+
+
+def test_every_option_the_library_accepts_is_documented():
+    """kr_create rejects option names it does not know (krotov_hip.hip, kr_option_names); INTEGRATION.md is where an integrator looks them
+    up: every accepted name must appear there as KROTOV_HIP_<NAME> (the environment spelling)."""
+    import re
+    src = open(os.path.join(ROOT, "krotov.jl_amd", "csrc", "krotov_hip.hip")).read()
+    body = re.search(r"kr_option_names\[\]\s*=\s*\{(.*?)\};", src, re.S).group(1)
+    names = re.findall(r'"([A-Z0-9_]+)"', body)
+    assert len(names) > 30
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in names if ("KROTOV_HIP_" + n) not in doc]
+    assert not missing, missing
