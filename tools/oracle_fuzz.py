@@ -30,6 +30,8 @@ for it in range(count):
     NS = [1, 2, 3, 5, 8, 9, 16, 17, 24, 32, 33, 48, 64, 65, 80, 100, 128, 130, 160, 200, 256, 257, 300]
     if os.environ.get("ORACLE_FUZZ_NMAX"):   # (the oracle's exact propagators cost seconds per shape at N >= 200: the test suite stays below)
         NS = [n for n in NS if n <= int(os.environ["ORACLE_FUZZ_NMAX"])]
+    if os.environ.get("ORACLE_FUZZ_NMIN"):   # (large state dimensions only: the row-split kernels of N > 128)
+        NS = [n for n in NS if n >= int(os.environ["ORACLE_FUZZ_NMIN"])]
     N = int(rng.choice(NS))
     kmax = 300 if N <= 64 else (64 if N <= 130 else (24 if N <= 256 else 6))
     K = int(rng.integers(1, kmax + 1))
