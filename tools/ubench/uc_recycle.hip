@@ -128,7 +128,7 @@ static void groups(int handles, bool pool, bool in_turn = false) {
     unsigned rs = 99u;
     for (int it = 0; it < handles; ++it) {
         rs = rs * 1664525u + 1013904223u;
-        const bool single = ((rs >> 5) % 4 == 0);            // some handles have one shard only
+        const bool single = getenv("UC_SINGLE") ? true : ((rs >> 5) % 4 == 0);   // some handles have one shard only (UC_SINGLE=1: all)
         const int P = ((rs >> 20) % 3 == 0) ? 64 : 2 + (int)((rs >> 8) % 60);
         const bool uc = P >= 64 && g_kind != 2;   // (pinned host memory: only the small block is special)
         const int S = single ? 1 : 2;
@@ -142,9 +142,12 @@ static void groups(int handles, bool pool, bool in_turn = false) {
             } else CK(hipMalloc((void **)&mail[s], WORDS * 8));
             CK(hipMemset(mail[s], 0, WORDS * 8));
             CK(hipMalloc((void **)&res[s], 64 * 4));
-            if (pool && !small_pool.empty()) { xm[s] = small_pool.back(); small_pool.pop_back(); }
-            else special_malloc(&xm[s], 2560);
-            CK(hipMemset(xm[s], 0, 2560));
+            xm[s] = nullptr;
+            if (!getenv("UC_NOSMALL")) {   // (UC_NOSMALL=1: no 2.5 KB uncached block beside the mailbox)
+                if (pool && !small_pool.empty()) { xm[s] = small_pool.back(); small_pool.pop_back(); }
+                else special_malloc(&xm[s], 2560);
+                CK(hipMemset(xm[s], 0, 2560));
+            }
             CK(hipDeviceSynchronize());
         }
         for (int call = 0; call < 3; ++call) {
@@ -170,7 +173,7 @@ static void groups(int handles, bool pool, bool in_turn = false) {
             for (int i = 0; i < 3; ++i) CK(hipFree(nb[s][i]));
             CK(hipFree(res[s]));
             if (uc && pool) big_pool.push_back(mail[s]); else if (uc) special_free(mail[s]); else CK(hipFree(mail[s]));
-            if (pool) small_pool.push_back(xm[s]); else special_free(xm[s]);
+            if (xm[s]) { if (pool) small_pool.push_back(xm[s]); else special_free(xm[s]); }
             CK(hipStreamDestroy(st[s]));
         }
     }
