@@ -13,6 +13,7 @@
 //           (phase 1 with ordinary blocks only)
 //   mode 7: the library's device list (see groups() below), everything freed; mode 8: uncached blocks kept and reused;
 //   mode 10: 960 ordinary blocks of random sizes allocated and freed first, then mode 8 in turn (uncached blocks allocated LATE in a process)
+//   mode 11: one handle at a time: an uncached mailbox used and freed, then a 32 MB ordinary block that may cover its address (see big_after_uc)
 //   mode 9: as 7, but the two shards' exchanges run one after the other from the main thread (no second thread, nothing concurrent)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -179,11 +180,57 @@ static void groups(int handles, bool pool, bool in_turn = false) {
     }
 }
 
+// mode 11: ONE handle at a time, as a single kr_create / kr_destroy sequence does it: an uncached mailbox is used and freed, then a LARGE
+// ordinary block (32 MB: served by the driver directly, not from the runtime's cached fragments -- the library's state storage is of that
+// size) is allocated; where it covers the address the uncached block had, the exchange runs exactly there, else at its start.
+static void big_after_uc(int handles) {
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    unsigned *res;
+    CK(hipMalloc((void **)&res, 64 * 4));
+    unsigned rs = 31u;
+    int covered = 0;
+    for (int it = 0; it < handles; ++it) {
+        rs = rs * 1664525u + 1013904223u;
+        const int P = 2 + (int)((rs >> 8) % 60);
+        unsigned long long *uc = nullptr;
+        CK(hipExtMallocWithFlags((void **)&uc, WORDS * 8, hipDeviceMallocUncached));
+        CK(hipMemset(uc, 0, WORDS * 8));
+        int gu, mi;
+        one_exchange(st, uc, res, P, (unsigned)(it * 8 + 1), &gu, &mi);
+        if (gu || mi) { g_bad++; printf("handle %d uncached mailbox %p: %d gave up, %d missing\n", it, (void *)uc, gu, mi); }
+        CK(hipFree(uc));
+        char *big = nullptr;
+        const size_t bytes = getenv("UC_BIG_KB") ? (size_t)atol(getenv("UC_BIG_KB")) << 10 : (size_t)32 << 20;   // (UC_BIG_KB: another size)
+        CK(hipMalloc((void **)&big, bytes));
+        CK(hipMemset(big, 0, bytes));
+        CK(hipDeviceSynchronize());
+        const bool over = (char *)uc >= big && (char *)uc + WORDS * 8 <= big + bytes;
+        covered += over ? 1 : 0;
+        unsigned long long *mail = over ? uc : (unsigned long long *)big;
+        for (int call = 0; call < 3; ++call) {
+            one_exchange(st, mail, res, P, (unsigned)(it * 8 + 2 + call), &gu, &mi);
+            if (gu || mi) {
+                g_bad++;
+                printf("handle %d call %d: ordinary 32 MB block %p, exchange at %p (%s the freed uncached block's address), P = %d: %d workgroups gave up, %d of %d words missing in memory\n",
+                       it, call, (void *)big, (void *)mail, over ? "AT" : "not at", P, gu, mi, REPL * P);
+                fflush(stdout);
+            }
+        }
+        g_handles++;
+        CK(hipFree(big));
+    }
+    printf("big block covered the freed uncached block's address in %d of %d handles\n", covered, handles);
+    CK(hipFree(res));
+    CK(hipStreamDestroy(st));
+}
+
 int main(int argc, char **argv) {
     const int handles = argc > 1 ? atoi(argv[1]) : 400, mode = argc > 2 ? atoi(argv[2]) : 0, threads = argc > 3 ? atoi(argv[3]) : 2;
     if (getenv("UC_KIND")) g_kind = !strcmp(getenv("UC_KIND"), "finegrained") ? 1 : !strcmp(getenv("UC_KIND"), "host") ? 2 : 0;
     CK(hipSetDevice(0));
-    if (mode == 10) {   // ordinary blocks of many sizes allocated and freed first, THEN the pooled pattern: uncached blocks that are allocated late
+    if (mode == 11) big_after_uc(handles);
+    else if (mode == 10) {   // ordinary blocks of many sizes allocated and freed first, THEN the pooled pattern: uncached blocks that are allocated late
         std::vector<void *> v;
         unsigned rs = 5u;
         for (int round = 0; round < 40; ++round) {
