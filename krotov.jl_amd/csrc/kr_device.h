@@ -166,6 +166,19 @@ __device__ __forceinline__ KrEcon kr_econ_select(const double ec, const double t
 
 __device__ __forceinline__ unsigned long long kr_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 
+// Pulse coherence word of a workgroup (KrSweepArgs::coh): two 32-bit halves, each rotated and mixed with one half of the new value --
+// five full-rate vector instructions per pulse value on every lane, no branch, no scalar registers (the first version kept the word in
+// scalar registers: the update kernels sit at the SGPR limit, and the extra spills to vector lanes cost C3 3 % -- 5.18 -> 5.33 us per
+// step, same-box A/B).  Order-sensitive; every bit of every value counts.  `fault`: the planted fault of the tests (option PULSE_FAULT).
+struct KrPulseFold { unsigned a, b; };
+__device__ __forceinline__ void kr_pulse_fold_v(KrPulseFold &f, const double v, const bool fault = false) {
+    const unsigned lo = (unsigned)__double2loint(v) ^ (fault ? 1u : 0u), hi = (unsigned)__double2hiint(v);
+    const unsigned ra = __builtin_amdgcn_alignbit(f.a, f.a, 19), rb = __builtin_amdgcn_alignbit(f.b, f.b, 25);   // rotate left by 13 / 7
+    f.a = (ra ^ lo) + f.b;
+    f.b = rb ^ hi;
+}
+__device__ __forceinline__ unsigned long long kr_pulse_word(const KrPulseFold &f) { return (((unsigned long long)f.b << 32) | f.a) | (1ull << 63); }
+
 typedef __attribute__((address_space(1))) unsigned long long kr_gu64;
 typedef __attribute__((address_space(1))) unsigned kr_gu32;
 
@@ -627,8 +640,8 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
     const unsigned tag = a.epoch_base + (unsigned)n + 1u;
     const int par = (int)(tag & 1u);                       // buffer of the mailbox between GPUs (xmail)
     // mailbox inside the GPU: buffer and phase from the step index of THIS launch (the mailbox is zeroed in front of it)
-    const int lpar = n & 1;
-    const unsigned phase = (((unsigned)n >> 1) & 1u) ^ 1u;
+    const int lpar = kr_mail_buffer((unsigned)n);
+    const unsigned phase = kr_mail_phase((unsigned)n);
     const unsigned sgran = xlocal ? (unsigned)KR_SLOT_GRANULES_LOCAL : (unsigned)KR_SLOT_GRANULES;   // words between slots
 
     constexpr bool EARLY = !KrIsNoWork<F>::value;   // a window exists: overlap the first poll pass with it
@@ -1005,6 +1018,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     }
     const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
     double ec_nx = econ_rows ? econ_rows[0] : 0.0;
+    KrPulseFold pfold = {0u, 0u};   // coherence word: every pulse value this workgroup formed, folded in step order
     for (int n = 0; n < NT; ++n) {
         const double dt = dt_nx;
         const double ec = ec_nx;
@@ -1160,6 +1174,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dt));
                 theta += fabs(e[l]) * gx.nrm[1 + l];
                 if (wg == 0 && memwave && lane == 0) a.eps_new[(size_t)l * NT + n] = e[l];
+                kr_pulse_fold_v(pfold, e[l], a.rs_fault == 2 && wg == 1 && n == 3);
             }
         }
         theta *= fabs(dt);
@@ -1279,24 +1294,27 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
     }
+    if (a.coh && tid == 0) a.coh[wg] = kr_pulse_word(pfold);   // (bit 63: a workgroup that never got here leaves the zero of the launch's memset)
 }
 
 // ---- launcher table for one NP ---------------------------------------------------------------
 #include "kr_device_prop.h"
 // propagator build: matrix cores for NP = 64 (KROTOV_HIP_EXPM_MFMA=0 at kr_create selects the VALU kernel)
 template <int NP, int LM, int CB>
-static void kr_launch_expm(int grid, hipStream_t s, const KrSweepArgs *a) {
+static hipError_t kr_launch_expm(int grid, hipStream_t s, const KrSweepArgs *a) {
     if constexpr (NP == 64) {
         if (a->use_mfma) {
             constexpr size_t lds = (size_t)4 * 64 * KR_YS * sizeof(double);
             // (per kernel AND device: kr_raise_dynamic_lds; on failure the VALU build kernel below carries the sweep)
             if (kr_raise_dynamic_lds((const void *)kr_expm_mfma64<LM>, (int)lds) == hipSuccess) {
                 kr_launch_kernel((kr_expm_mfma64<LM>), grid, 256, lds, s, *a);
-                return;
+                return hipSuccess;
             }
         }
     }
+    if (a->u_layout == 2) return hipErrorInvalidValue;   // the fragment order of the time-blocked sweep is written by the matrix-core build only
     kr_launch_kernel((kr_expm_batch<NP, LM, CB>), grid, KrGeom<NP, LM, 1>::THREADS, 0, s, *a);
+    return hipSuccess;
 }
 
 template <int NP>
@@ -1321,7 +1339,7 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
             default: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 1, 1, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
             } \
         } \
-        else if (kind == 2) { kr_launch_expm<NP, LM, CB>(grid, s, a); }                              \
+        else if (kind == 2) { const hipError_t ee_ = kr_launch_expm<NP, LM, CB>(grid, s, a); if (ee_ != hipSuccess) return ee_; } \
         else kr_launch_kernel((kr_sweep_apply<NP, KTv>), grid, KrApplyGeom<NP>::THREADS, 0, s, *a);      \
         return hipGetLastError();                                                                 \
     }

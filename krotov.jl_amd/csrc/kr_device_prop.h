@@ -470,6 +470,14 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
         }
         return;
     }
+    if (a.u_layout == 2) {   // fragment order of the time-blocked sweep (kr_device_tblock.h): [(16 w' + t) * 64 + lane] = {Ur, Ui} of U[16 w' + (lane & 15)][4 t + (lane >> 4)]
+        for (int e = tid; e < 4096; e += 256) {
+            const int l = e & 63, t = (e >> 6) & 15, wt = e >> 10;
+            const int r = 16 * wt + (l & 15), cc = 4 * t + (l >> 4);
+            Un[e] = make_double2(KR_YR(cur)[r * KR_YS + cc], KR_YI(cur)[r * KR_YS + cc]);
+        }
+        return;
+    }
     // u_layout = 0: thread-major pack of kr_sweep_apply: Upack[jj * 256 + i*4 + jq] = U[i][jq*16 + jj]
     for (int t2 = tid; t2 < RT_A; t2 += 256) {   // consumer thread t2 = (i, jq)
         const int i = t2 / JQ_A, jq = t2 % JQ_A;

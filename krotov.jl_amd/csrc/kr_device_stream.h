@@ -220,6 +220,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
     for (int l = 0; l < LMAX; ++l) gint[l] = 0.0;
     __syncthreads();
     int cur = 0;
+    KrPulseFold pfold = {0u, 0u};   // coherence word (kr_device.h: kr_pulse_fold_v)
     for (int n = 0; n < NT; ++n) {
         const double dt = a.dt[n];
         const double ec = econ_rows ? econ_rows[(size_t)n * KR_ECON_W] : 0.0;
@@ -267,6 +268,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(al[l], __dmul_rn(ad, ad)), dt));
                 theta += fabs(e[l]) * gx.nrm[1 + l];
                 if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = e[l];
+                kr_pulse_fold_v(pfold, e[l], a.rs_fault == 2 && wg == 1 && n == 3);
             }
         }
         theta *= fabs(dt);
@@ -351,6 +353,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
     }
+    if (a.coh && tid == 0) a.coh[wg] = kr_pulse_word(pfold);
 }
 
 template <int NP>

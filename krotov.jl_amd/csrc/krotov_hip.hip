@@ -87,6 +87,11 @@ struct kr_handle {
     double2 *psi0_d = nullptr, *tgt_d = nullptr, *psiT_d = nullptr, *chiT_d = nullptr, *X_d = nullptr, *Phi_d = nullptr;
     double2 *tau_d = nullptr, *tausum_d = nullptr;
     double2 *U_d = nullptr;   // precomputed step propagators of the known-pulse sweeps (N <= 64), or nullptr
+    // known-pulse sweeps in blocks of time (kr_device_tblock.h, NP = 64): tb_S steps per block (0: sequential apply sweep), block
+    // propagators [G][NB][4096], states at the block boundaries [NB + 1][Kp][N], the trajectory ranges a workgroup carries
+    int tb_S = 0, tb_NB = 0, tb_nitems = 0;
+    double2 *tb_P_d = nullptr, *tb_bound_d = nullptr;
+    int *tb_items_d = nullptr;
     bool precomp = false;
     bool use_mfma = true;
     // update sweep on the matrix cores (kr_device_mfma.h, NP = 64): KT = 2 * tiles trajectories per 256-thread workgroup
@@ -105,10 +110,13 @@ struct kr_handle {
     // host timeline of the last update sweep (ms since the library was loaded):
     // a timeout between shards of one handle is reported with every shard's line (group_run)
     double tl_launch0 = 0, tl_launch1 = 0, tl_wait0 = 0, tl_wait1 = 0;
-    bool peers_cached = false;   // peer mailboxes come from the process-wide cache of IPC mappings: never closed by this handle
+    bool peer_cached[8] = {false, false, false, false, false, false, false, false};   // peer mailbox r comes from the process-wide cache of IPC mappings: never closed by this handle
     int mail_kind = 0, xmail_kind = 0;   // 0 ordinary hipMalloc, 1 uncached, 2 fine-grained (special_alloc: returned to the pool, not freed)
     size_t xmail_bytes = 0;
     unsigned last_epoch_base = 0;   // tag base of the last update launch (the timeout report prints the tags it expected)
+    unsigned long long xmail_gen = 0;   // how often this process has handed out the xmail block (special_alloc): seeds the tag base of the handle
+    bool pulse_check = true;        // pulse coherence words compared after every update sweep of the N <= 64 / streamed kernels (kr_pulse_check)
+    int quarantined = 0;            // mailbox blocks that failed the self-test of kr_create and were set aside
     bool peers_connected = false;
     bool peers_in_process = false;   // peer mailboxes are plain pointers of sibling shards (device list), not IPC mappings
     unsigned *status_d = nullptr;
@@ -254,8 +262,8 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
 // is the fallback for the lab.  kr_create rejects a name that is not in this list (a typo would otherwise be silently ignored).
 static const char *const kr_option_names[] = {
     "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
-    "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "PACK_CHECK", "PACK_FAULT", "POLL_DELAY", "PRECOMP", "ROWSPLIT",
-    "RS512", "RS_BATCH", "RS_FAULT", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "SHARD_SKEW_MS", "STAMPS", "UC_POOL", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY", "ZERO_KERNEL", "ZERO_SYNC"};
+    "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "MAIL_SELFTEST", "MAIL_FAULT", "PACK_CHECK", "PACK_FAULT", "POLL_DELAY", "PRECOMP", "PULSE_CHECK", "PULSE_FAULT", "RCCL_CACHE", "ROWSPLIT",
+    "RS512", "RS_BATCH", "RS_FAULT", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "SHARD_SKEW_MS", "STAMPS", "TBLOCK", "TBLOCK_MIN_NT", "UC_POOL", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY", "ZERO_KERNEL", "ZERO_SYNC"};
 static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
     out.clear();
     if (!text) return true;
@@ -448,6 +456,56 @@ __global__ void kr_rowsplit_check(const unsigned long long *words, int tiles, in
     bool bad = (ref == 0ull);
     for (int r = 1; r < R; ++r) bad = bad || (words[(size_t)t * R + r] != ref);
     if (bad && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 6u; status[2] = (unsigned)t; }
+}
+
+// After an update sweep of the register-resident / matrix-core / streamed kernels (N <= 64 and the streamed fallback): every workgroup
+// formed eps_new for itself from the totals IT gathered and folded all N_T x L values into one word (KrSweepArgs::coh); the P words must
+// be equal -- a workgroup that summed a stale or lost partial sum once has propagated with another pulse than its neighbours
+// (status code 8).  optimize.jl:351-358 has ONE pulse value per step.
+__global__ __launch_bounds__(256) void kr_pulse_check(const unsigned long long *words, int P, unsigned *status) {
+    const unsigned long long ref = words[0];
+    bool bad = (ref >> 63) == 0ull;
+    int who = 0;
+    for (int q = threadIdx.x; q < P; q += 256) if (words[q] != ref) { bad = true; who = q; }
+    if (bad && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 8u; status[2] = (unsigned)who; }
+}
+
+// Self-test of a freshly allocated mailbox (kr_create; round 5): the exchange pattern of the sweeps on the mailbox's own words -- every
+// one of P workgroups stores one word per slot it owns into every replica (write-through stores), then polls ALL slots of the replica of
+// the XCD it runs on (loads that bypass the vector L1) until every word carries this round's value; two rounds with different values.
+// What it catches ("blocks that follow a freed uncached block"): an address range on which single stores never reach memory,
+// or reach it and stay invisible to some XCDs.  Bounded: a workgroup that does not see every word within `ticks` sets status code 9.
+// Layout under test: `replicas` copies `rstride` words apart, slot q at q * sgran (+ w for the `width` words of a slot).
+__global__ __launch_bounds__(64) void kr_mail_selftest(unsigned long long *mail, int P, int replicas, size_t rstride, int sgran, int width,
+                                                        unsigned long long ticks, int fault, unsigned *status) {
+    const int wg = blockIdx.x, lane = threadIdx.x;
+    unsigned xcc;
+    asm("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int rep = (int)(xcc & 7u) % replicas;
+    for (unsigned round = 1; round <= 2; ++round) {
+        const unsigned long long val = 0x5a17000000000000ull | ((unsigned long long)round << 40);
+        for (int e = lane; e < replicas * width; e += 64) {
+            const int r = e / width, w = e % width;
+            if (fault && round == 2 && wg == P / 2 && r == replicas - 1) continue;   // (tests: one word never published)
+            __hip_atomic_store(mail + (size_t)r * rstride + (size_t)wg * sgran + w, val | (unsigned long long)(wg * 8 + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            bool ok = true;
+            for (int e = lane; e < P * width; e += 64) {
+                const int q = e / width, w = e % width;
+                const unsigned long long got = __hip_atomic_load(mail + (size_t)rep * rstride + (size_t)q * sgran + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (a faster workgroup may already have published its word of round 2)
+                ok = ok && ((got & ~(3ull << 40)) == (0x5a17000000000000ull | (unsigned long long)(q * 8 + w))) && (((got >> 40) & 3ull) >= round);
+            }
+            if (__all(ok)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) {
+                if (lane == 0 && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 9u; status[2] = (unsigned)wg | (round << 16) | ((unsigned)rep << 24); }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
 }
 
 __global__ void kr_tau_kernel(const double2 *tgt, const double2 *psi, double2 *tau, int N, int K) {
@@ -907,19 +965,22 @@ extern "C" int kr_abi_version(void) { return KR_ABI_VERSION; }
 
 extern "C" const char *kr_last_error(const kr_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-static void special_release(kr_handle *h, void *p, size_t bytes, int kind);
+static void special_release(kr_handle *h, void *p, size_t bytes, int kind, unsigned long long gen);
+static void rccl_release(kr_handle *h);
 static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->pack_words_d, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d, h->skw_d,
-                    h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d};
+                    h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d,
+                    h->tb_P_d, h->tb_bound_d, h->tb_items_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (h->peers_connected && !h->peers_in_process && !h->peers_cached)   // (cached mappings stay open: ipc_open)
+    if (h->peers_connected && !h->peers_in_process)   // (cached mappings stay open: ipc_open)
         for (int r = 0; r < h->cfg.world; ++r)
-            if (r != h->cfg.rank && h->peer_xmail[r]) (void)hipIpcCloseMemHandle(h->peer_xmail[r]);
-    if (h->mail_d) { if (h->mail_kind) special_release(h, h->mail_d, h->mail_words * sizeof(unsigned long long), h->mail_kind); else (void)hipFree(h->mail_d); }
-    if (h->xmail_d) { if (h->xmail_kind) special_release(h, h->xmail_d, h->xmail_bytes, h->xmail_kind); else (void)hipFree(h->xmail_d); }
+            if (r != h->cfg.rank && h->peer_xmail[r] && !h->peer_cached[r]) (void)hipIpcCloseMemHandle(h->peer_xmail[r]);
+    if (h->mail_d) { if (h->mail_kind) special_release(h, h->mail_d, h->mail_words * sizeof(unsigned long long), h->mail_kind, 0); else (void)hipFree(h->mail_d); }
+    // the mailbox between GPUs goes back to the pool WHATEVER its kind: peers in other processes may still be storing into it
+    if (h->xmail_d) special_release(h, h->xmail_d, h->xmail_bytes, h->xmail_kind, h->xmail_gen);
     if (h->du_host) (void)hipHostFree(h->du_host);
-    if (h->rccl_comm && kr_rccl()) (void)kr_rccl()->CommDestroy(h->rccl_comm);
+    rccl_release(h);
     for (auto &pool : h->ev) for (auto &e : pool) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
@@ -947,31 +1008,46 @@ static hipError_t dalloc(T **p, size_t count) {
 // process-wide pool (per device, kind and size) and the next handle that asks for the same takes it from there (KROTOV_HIP_UC_POOL=0:
 // hipFree as before).  See DESIGN.md, "device lists": [round 4] with blocks of both kinds allocated and freed in turn by the handles
 // of one process, partial sums published into an ORDINARY mailbox went missing.
-struct KrSpecialBlock { void *p; int device, kind; size_t bytes; };
+struct KrSpecialBlock { void *p; int device, kind; size_t bytes; unsigned long long gen; };
 static std::mutex g_special_mtx;
 static std::vector<KrSpecialBlock> g_special_free;
-static hipError_t special_alloc(kr_handle *h, void **p, size_t bytes, int kind /* 1 uncached, 2 fine-grained */) {
+// kind: 1 uncached, 2 fine-grained, 0 ordinary device memory (the mailbox between GPUs when neither special kind is available: a block
+// peers store into must outlive every kernel of theirs that may still be spinning towards it -- other processes cannot be waited for,
+// so such a block goes back to the pool whatever its kind).  *gen (optional): how often this process has handed the block out, counting
+// from 1 -- ranks mix the generations of all their mailboxes into the tag base of a handle (kr_ipc_connect), so that a store that a late
+// peer of an EARLIER handle still sends into a recycled block never carries a tag the new handle waits for.
+static hipError_t special_alloc(kr_handle *h, void **p, size_t bytes, int kind, unsigned long long *gen = nullptr) {
     if (opt_int(h, "UC_POOL", 1) != 0) {
         std::lock_guard<std::mutex> g(g_special_mtx);
         for (size_t i = 0; i < g_special_free.size(); ++i)
             if (g_special_free[i].device == h->device && g_special_free[i].kind == kind && g_special_free[i].bytes == bytes) {
                 *p = g_special_free[i].p;
+                if (gen) *gen = g_special_free[i].gen + 1;
                 g_special_free.erase(g_special_free.begin() + (long)i);
                 return hipSuccess;
             }
     }
+    if (gen) *gen = 1;
+    if (kind == 0) return hipMalloc(p, bytes);
     return hipExtMallocWithFlags(p, bytes, kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
 }
-static void special_release(kr_handle *h, void *p, size_t bytes, int kind) {
+static void special_release(kr_handle *h, void *p, size_t bytes, int kind, unsigned long long gen = 0) {
     if (!p) return;
     if (opt_int(h, "UC_POOL", 1) != 0) {
         try {
             std::lock_guard<std::mutex> g(g_special_mtx);
-            g_special_free.push_back({p, h->device, kind, bytes});
+            g_special_free.push_back({p, h->device, kind, bytes, gen});
             return;
         } catch (...) {}
     }
     (void)hipFree(p);
+}
+// A block that failed the self-test of kr_create is never used and never handed back (the runtime would serve the next request from
+// the same address range): it stays allocated for the life of the process.
+static std::mutex g_quarantine_mtx;
+static std::vector<void *> g_quarantine;
+static void quarantine_block(void *p) {
+    try { std::lock_guard<std::mutex> g(g_quarantine_mtx); g_quarantine.push_back(p); } catch (...) {}
 }
 static hipError_t alloc_mailbox(kr_handle *h, unsigned long long **p, size_t words, int pollers) {
     const int mm = opt_int(h, "MAIL_MEM", pollers >= 64 ? 1 : 0);
@@ -982,6 +1058,16 @@ static hipError_t alloc_mailbox(kr_handle *h, unsigned long long **p, size_t wor
         (void)hipGetLastError();  // not available on this device/driver: fall back to ordinary memory
     }
     return dalloc(p, words);
+}
+
+// one run of kr_mail_selftest on a region; st[0] != 0 afterwards: the region failed (st[2]: workgroup | round << 16 | replica << 24)
+static int mailbox_selftest(kr_handle *h, unsigned long long *base, int P, int replicas, size_t rstride, int sgran, int width, int fault, unsigned (&st)[KR_STATUS_WORDS]) {
+    hipLaunchKernelGGL(kr_mail_selftest, dim3(P), dim3(64), 0, h->own_stream, base, P, replicas, rstride, sgran, width, (unsigned long long)2000000ull /* 20 ms */, fault, h->status_d);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(st, h->status_d, sizeof st, hipMemcpyDeviceToHost, h->own_stream));
+    HIPCHK(h, hipStreamSynchronize(h->own_stream));
+    if (st[0] != 0) HIPCHK(h, hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
+    return KR_OK;
 }
 
 static int calibrate_exchange(kr_handle *h);  // defined below, next to launch_update
@@ -1070,6 +1156,8 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     if (rc != KR_OK) return bail(rc);
     CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
+    CHK(dalloc(&h->status_d, KR_STATUS_WORDS));
+    CHK(hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
 
     const int N = cfg->N, NT = cfg->NT, L = cfg->L, NP = h->NP;
     const size_t nn = (size_t)N * N;
@@ -1281,6 +1369,18 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         h->xcd_group = ((h->P / h->R) % 8 == 0) && opt_int(h, "XCD_GROUP", 1) != 0;
         CHK(dalloc(&h->gmail_d, h->gmail_words));
         CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
+        if (opt_int(h, "MAIL_SELFTEST", 1) != 0) {   // the all-gather's mailbox: P words spread over the whole block
+            unsigned st[KR_STATUS_WORDS] = {};
+            rc = mailbox_selftest(h, h->gmail_d, h->P, 1, 0, (int)std::max<size_t>(1, h->gmail_words / (size_t)h->P), 1, 0, st);
+            if (rc != KR_OK) return bail(rc);
+            if (st[0] != 0) {
+                quarantine_block(h->gmail_d); h->gmail_d = nullptr;
+                fail(h, KR_ERR_INTERNAL, "kr_create: the freshly allocated all-gather mailbox failed its self-test (workgroup %u did not see every published word within 20 ms): "
+                     "device memory of this process loses stores or hides them from some XCDs; the block is set aside -- call kr_create again", st[2] & 0xffffu);
+                return bail(KR_ERR_INTERNAL);
+            }
+            CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
+        }
         if (h->rs_sets > 1) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * 4 /* KR_PAIR_MAX_SETS */ * 2 * NP));
         if (h->rs_turns > 0) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * KR_RS_MAX_TURNS * NP));
     }
@@ -1307,6 +1407,32 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         h->precomp = h->fast_ok && (NP <= 64) && opt_int(h, "PRECOMP", 1) != 0 && ubytes <= ((size_t)8 << 30);
         h->use_mfma = opt_int(h, "EXPM_MFMA", 1) != 0;
         if (h->precomp) CHK(dalloc(&h->U_d, (size_t)G * NT * NP * NP));
+        // ... and in blocks of time (round 5): NP = 64 with the matrix-core propagator build, grids long enough for the two extra
+        // passes to pay (TBLOCK_MIN_NT), the boundary buffer within a budget.  KROTOV_HIP_TBLOCK = steps per block, 0 = off.
+        const int S = opt_int(h, "TBLOCK", 8);
+        if (h->precomp && NP == 64 && h->use_mfma && S >= 2 && S <= 64 && NT >= opt_int(h, "TBLOCK_MIN_NT", 64) && NT >= 2 * S) {
+            const int NB = (NT + S - 1) / S;
+            const size_t bbytes = (size_t)(NB + 1) * h->Kp * N * sizeof(double2);
+            if (bbytes <= ((size_t)4 << 30)) {
+                h->tb_S = S; h->tb_NB = NB;
+                CHK(dalloc(&h->tb_P_d, (size_t)G * NB * 4096));
+                CHK(dalloc(&h->tb_bound_d, (size_t)(NB + 1) * h->Kp * N));
+                // items: runs of internal slots with one generator (the slots are grouped by generator, every group padded to whole
+                // tiles with zero trajectories), cut into pieces of at most 64
+                std::vector<int> items;
+                const int tiles = (int)wg_gen.size(), ktile = h->KTILE;
+                int t0 = 0;
+                while (t0 < tiles) {
+                    int t1 = t0;
+                    while (t1 < tiles && wg_gen[t1] == wg_gen[t0]) ++t1;
+                    for (int k0 = t0 * ktile; k0 < t1 * ktile; k0 += 64) { items.push_back(k0); items.push_back(std::min(64, t1 * ktile - k0)); items.push_back(wg_gen[t0]); items.push_back(0); }
+                    t0 = t1;
+                }
+                h->tb_nitems = (int)items.size() / 4;
+                CHK(dalloc(&h->tb_items_d, items.size()));
+                CHK(hipMemcpy(h->tb_items_d, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
+            }
+        }
     }
     CHK(dalloc(&h->tau_d, h->Kp));
     CHK(dalloc(&h->tausum_d, 1));
@@ -1315,34 +1441,65 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     CHK(hipMemset(h->psiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->chiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->gint_d, 0, std::max(L, KR_LMAX_CAP) * sizeof(double)));
-    h->mail_words = KR_MAIL_XTAB_OFF + KR_MAIL_XTAB_WORDS;  // 2 buffers x 8 replicas (one per XCD) x 64 KB (kr_exchange); tail: a poll pass
+    h->mail_words = KR_MAIL_COH_OFF + KR_MAIL_COH_WORDS;    // 2 buffers x 8 replicas (one per XCD) x 64 KB (kr_exchange); tail: a poll pass
                                                             // reads whole 64-slot chunks (kr_poll_pass); then the XCC-id table of the
                                                             // one-XCD placement (kr_sweep_update)
     // (the generic update kernels do not use this mailbox: any number of tiles -- N = 8, K = 8193 used to fail here)
     if (!h->gen_update && (size_t)h->P * 4 > KR_MAIL_RSTRIDE) { fail(h, KR_ERR_UNSUPPORTED, "%d workgroups do not fit one mailbox replica", h->P); return bail(KR_ERR_UNSUPPORTED); }
-    CHK(alloc_mailbox(h, &h->mail_d, h->mail_words, h->P));
-    CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
+    h->pulse_check = opt_int(h, "PULSE_CHECK", 1) != 0 && (size_t)h->P <= KR_MAIL_COH_WORDS;
+    // The mailbox of the per-step exchange, self-tested (kr_mail_selftest: the exchange's own store / poll pattern on both buffers and
+    // all replicas, ~50 us): a block on which stores get lost or stay invisible to some XCDs -- seen for blocks that reuse the address
+    // range of a freed uncached block, which this library no longer frees but another library of the process may -- is set aside and
+    // another one is asked for (three attempts; KROTOV_HIP_MAIL_SELFTEST=0 skips the test).
+    for (int attempt = 0;; ++attempt) {
+        CHK(alloc_mailbox(h, &h->mail_d, h->mail_words, h->P));
+        CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
+        if (h->gen_update || opt_int(h, "MAIL_SELFTEST", 1) == 0) break;
+        const int mf = opt_int(h, "MAIL_FAULT", 0);   // (tests: 1 = the first block fails, 2 = every block fails)
+        unsigned st[KR_STATUS_WORDS] = {};
+        for (int buf = 0; buf < 2 && st[0] == 0; ++buf) {
+            rc = mailbox_selftest(h, h->mail_d + (size_t)buf * KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE, h->P, KR_MAIL_REPLICAS, (size_t)KR_MAIL_RSTRIDE, h->LMAXv > 0 ? h->LMAXv : 2,
+                                  std::max(1, std::min(h->cfg.L, 4)), (mf == 2 || (mf == 1 && attempt == 0)) ? 1 : 0, st);
+            if (rc != KR_OK) return bail(rc);
+        }
+        if (st[0] == 0) { CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long))); break; }
+        quarantine_block(h->mail_d);   // never used, never freed
+        h->mail_d = nullptr;
+        h->quarantined++;
+        if (attempt == 2) {
+            fail(h, KR_ERR_INTERNAL, "kr_create: three freshly allocated mailboxes failed their self-test (workgroup %u, round %u, replica %u of the last one did not see every "
+                 "published word within 20 ms): device memory of this process loses stores or hides them from some XCDs; see INTEGRATION.md, \"freed uncached blocks\"",
+                 st[2] & 0xffffu, (st[2] >> 16) & 0xffu, st[2] >> 24);
+            return bail(KR_ERR_INTERNAL);
+        }
+    }
     CHK(dalloc(&h->debug_d, 8 + 8 * 1024));   // 8 phase stamps + per-workgroup arrival stamps of diagnostic builds (KR_ARRIVALS)
     CHK(hipMemset(h->debug_d, 0, (8 + 8 * 1024) * sizeof(unsigned long long)));
     h->debug_on = opt_int(h, "STAMPS", 0) != 0;
-    CHK(dalloc(&h->status_d, KR_STATUS_WORDS));
-    CHK(hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
     if (cfg->world > 1) {
         // inter-GPU mailbox: written by peers over xGMI, polled by this GPU's kernels -> uncached/fine-grained
         const size_t xwords = (size_t)2 * 8 * 2 * KR_LMAX_CAP + 2 * 8 * 4;   // update-sweep slots + tau slots (KR_XMAIL_TAU_OFF)
         // preference: uncached, then fine-grained, then plain device memory (peers always use system-scope atomics)
         h->xmail_bytes = xwords * sizeof(unsigned long long);
-        h->xmail_kind = 1;
-        if (special_alloc(h, (void **)&h->xmail_d, h->xmail_bytes, 1) != hipSuccess) {
+        for (int kind : {1, 2, 0}) {
+            h->xmail_kind = kind;
+            if (special_alloc(h, (void **)&h->xmail_d, h->xmail_bytes, kind, &h->xmail_gen) == hipSuccess) break;
             (void)hipGetLastError();
-            h->xmail_kind = 2;
-            if (special_alloc(h, (void **)&h->xmail_d, h->xmail_bytes, 2) != hipSuccess) {
-                (void)hipGetLastError();
-                h->xmail_kind = 0;
-                CHK(hipMalloc((void **)&h->xmail_d, h->xmail_bytes));
-            }
+            h->xmail_d = nullptr;
         }
+        if (!h->xmail_d) { fail(h, KR_ERR_HIP, "no device memory for the mailbox between GPUs"); return bail(KR_ERR_HIP); }
         CHK(hipMemset(h->xmail_d, 0, xwords * sizeof(unsigned long long)));
+        if (opt_int(h, "MAIL_SELFTEST", 1) != 0) {   // the mailbox between GPUs, as this GPU's workgroups see it
+            unsigned st[KR_STATUS_WORDS] = {};
+            rc = mailbox_selftest(h, h->xmail_d, 8, 1, 0, (int)(xwords / 8), 4, 0, st);
+            if (rc != KR_OK) return bail(rc);
+            if (st[0] != 0) {
+                quarantine_block(h->xmail_d); h->xmail_d = nullptr;
+                fail(h, KR_ERR_INTERNAL, "kr_create: the mailbox between GPUs failed its self-test (workgroup %u did not see every published word within 20 ms); the block is set aside -- call kr_create again", st[2] & 0xffffu);
+                return bail(KR_ERR_INTERNAL);
+            }
+            CHK(hipMemset(h->xmail_d, 0, xwords * sizeof(unsigned long long)));
+        }
         h->peer_xmail[cfg->rank] = h->xmail_d;
     }
     CHK(hipDeviceSynchronize());
@@ -1350,7 +1507,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     rc = calibrate_exchange(h);
     if (rc != KR_OK) return bail(rc);
     {   // kr_plan_description(): which kernels carry this problem, and why if not the persistent ones
-        char buf[800];
+        char buf[1400];
         const char *upd = h->gen_update ? "generic per-step kernels (kr_gen_partial/reduce/form/apply)"
                         : h->rowsplit ? (h->rs_pair ? "kr_rowsplit_pair_sweep (two interleaved trajectories per group)"
                                          : h->rs_turns > 0 ? "kr_rowsplit_turns_update (the groups of workgroups carry several trajectories in turn)" : "kr_rowsplit_sweep")
@@ -1360,10 +1517,12 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         static const char *const exn[] = {"auto", "mailbox", "rccl", "callback"};
         snprintf(buf, sizeof buf, "N=%d (padded %d) NT=%d K=%d (padded %d) L=%d G=%d rank %d/%d on device %d: update sweep = %s, %d workgroups x %d "
                  "trajectories, sets per workgroup %d, one-XCD placement %d, R=%d, HERM=%d, economized=%d, poll_delay=%d; known-pulse sweeps = %s; exchange = %s; spin bound %.0f ms; "
-                 "integrity checks: operator-copy checksums %s, group coherence words %s%s%s",
+                 "integrity checks: operator-copy checksums %s, group coherence words %s, pulse coherence words %s, mailbox self-test %s%s%s%s",
                  h->cfg.N, h->NP, h->cfg.NT, h->cfg.K, h->Kp, h->cfg.L, h->G, h->cfg.rank, h->cfg.world, h->device, upd, h->P, h->KTILE, h->rs_turns > 0 ? h->rs_turns : h->sets,
                  h->wg_stride > 1 ? 1 : 0, h->rowsplit ? h->R : 1, h->herm ? 1 : 0, (h->econ || h->econ_gen) ? 1 : 0, h->poll_delay, known, exn[h->exchange & 3], (double)h->spin_ticks / 1e5,
-                 h->pack_words_d ? "on" : "off", (h->rowsplit && h->R > 1) ? "on" : "n/a",
+                 h->pack_words_d ? "on" : "off", (h->rowsplit && h->R > 1) ? "on" : "n/a", (h->pulse_check && !h->rowsplit && !h->gen_update) ? "on" : "n/a",
+                 (h->gen_update || opt_int(h, "MAIL_SELFTEST", 1) == 0) ? "off" : (h->quarantined ? "passed after setting blocks aside" : "passed"),
+                 opt_int(h, "UC_POOL", 1) == 0 ? "; WARNING: UC_POOL=0 (diagnostics only): uncached mailboxes are freed again, and blocks that reuse their address range lose stores on this platform" : "",
                  h->plan_note.empty() ? "" : "; note: ", h->plan_note.c_str());
         h->plan_text = buf;
     }
@@ -1509,6 +1668,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.xcd_group = h->xcd_group ? 1 : 0;
     a.rs_sets = h->rs_sets;
     a.rs_fault = opt_int(h, "RS_FAULT", 0);
+    if (opt_int(h, "PULSE_FAULT", 0) != 0) a.rs_fault = 2;   // (tests: workgroup 1 folds a wrong pulse value into its coherence word at step 3)
     a.rs_scratch = h->rs_scratch_d;
     a.pack_stride = h->pack_stride;
     a.Hdense = h->Hdense_fw;
@@ -1836,7 +1996,8 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         const int mfa = opt_int(h, "MFMA_APPLY", -1);
         const bool mf_apply = h->NP == 64 && h->use_mfma && (mfa == 1 || (mfa == -1 && h->KT >= 2)) && (h->Kp % 2 == 0) &&
                               (h->G == 1 || h->KT % 2 == 0);
-        a.u_layout = mf_apply ? 1 : 0;
+        const bool tb = h->tb_S > 0;   // blocks of time (kr_device_tblock.h)
+        a.u_layout = tb ? 2 : (mf_apply ? 1 : 0);
         if (h->econ && h->NP == 64) {   // economized polynomial of every step (the pulses are known exactly: margin = rounding only;
                                         // smaller N: building the rows costs what the saved product gains -- C2 +6 us per sweep)
             const int rows = h->G * h->cfg.NT;
@@ -1846,28 +2007,53 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
             a.econ = h->econ_d;
         }
         HIPCHK(h, h->launch(h->LMAXv, std::min(h->KT, 4), 2, h->cfg.NT * h->G, h->stream, &a));
-        if (mf_apply) {
-            int kt_a = (h->KT % 2 == 0) ? std::min(h->KT, 4) : 2;
-            const int want_a = opt_int(h, "MFMA_APPLY_KT", 0);   // (tuning knob: 2 or 4 trajectories per workgroup)
-            if ((want_a == 2 || want_a == 4) && h->Kp % want_a == 0 && (h->G == 1 || h->KT % want_a == 0 || want_a % h->KT == 0) && (h->G == 1 || want_a <= h->KT)) kt_a = want_a;
-            a.gen_div = std::max(1, h->KT * h->sets / kt_a);
-            HIPCHK(h, kr_launch_mf64(2, kt_a / 2, 3, h->Kp / kt_a, h->stream, &a));
-            return ev_mark(h, which_ev, true);
-        }
-        // The apply sweep is bound by streaming U_n (NP^2 * 16 B per workgroup per step) from L2: with a shared
-        // generator, wider tiles (more trajectories per workgroup, fewer workgroups) cut that traffic.
-        int kt_apply = std::min(h->KT, 4);   // (KT = 8 exists only for the matrix-core update sweep)
-        if (h->G == 1) {
-            const int want = opt_int(h, "APPLY_KT", 0);
-            for (int cand : {4, 2}) {
-                if (cand <= kt_apply) break;
-                const bool pick = (cand == want);  // measured at C3: KT 1 -> 1.24 ms, 2 -> 1.44 ms, 4 -> 2.03 ms per sweep: default = the handle's KT
-                if (pick && h->Kp % (h->SG * cand) == 0) { kt_apply = cand; break; }
+        // the sequential apply sweep over q.NT propagators q.U (the step propagators, or the block propagators of the time-blocked sweep)
+        auto apply_seq = [&](KrSweepArgs &q) -> int {
+            if (mf_apply) {
+                int kt_a = (h->KT % 2 == 0) ? std::min(h->KT, 4) : 2;
+                const int want_a = opt_int(h, "MFMA_APPLY_KT", 0);   // (tuning knob: 2 or 4 trajectories per workgroup)
+                if ((want_a == 2 || want_a == 4) && h->Kp % want_a == 0 && (h->G == 1 || h->KT % want_a == 0 || want_a % h->KT == 0) && (h->G == 1 || want_a <= h->KT)) kt_a = want_a;
+                q.gen_div = std::max(1, h->KT * h->sets / kt_a);
+                HIPCHK(h, kr_launch_mf64(2, kt_a / 2, 3, h->Kp / kt_a, h->stream, &q));
+                return KR_OK;
+            }
+            // The apply sweep is bound by streaming U_n (NP^2 * 16 B per workgroup per step) from L2: with a shared
+            // generator, wider tiles (more trajectories per workgroup, fewer workgroups) cut that traffic.
+            int kt_apply = std::min(h->KT, 4);   // (KT = 8 exists only for the matrix-core update sweep)
+            if (h->G == 1) {
+                const int want = opt_int(h, "APPLY_KT", 0);
+                for (int cand : {4, 2}) {
+                    if (cand <= kt_apply) break;
+                    const bool pick = (cand == want);  // measured at C3: KT 1 -> 1.24 ms, 2 -> 1.44 ms, 4 -> 2.03 ms per sweep: default = the handle's KT
+                    if (pick && h->Kp % (h->SG * cand) == 0) { kt_apply = cand; break; }
+                }
+            }
+            q.gen_div = h->KT * h->sets / kt_apply;   // apply tiles per update tile (wg_gen is indexed by update tile)
+            if (q.gen_div < 1) q.gen_div = 1;
+            HIPCHK(h, h->launch(h->LMAXv, kt_apply, 3, h->Kp / (h->SG * kt_apply), h->stream, &q));
+            return KR_OK;
+        };
+        if (!tb) {
+            rc = apply_seq(a);
+            if (rc) return rc;
+        } else {
+            // (ii) block propagators, in the operand order of the sequential kernel that consumes them
+            KrSweepArgs pa = a;
+            pa.tb_NT = h->cfg.NT; pa.tb_S = h->tb_S; pa.u_layout = mf_apply ? 1 : 0;
+            HIPCHK(h, kr_launch_tblock(0, h->G * h->tb_NB, h->stream, &pa, h->tb_P_d));
+            // (iii) states at the block boundaries: the sequential sweep over the block propagators, in sweep order (dir = +1:
+            //       boundary b + 1 after block b), final states as before
+            KrSweepArgs q = a;
+            q.U = h->tb_P_d; q.NT = h->tb_NB; q.dir = +1; q.store = h->tb_bound_d; q.u_layout = mf_apply ? 1 : 0;
+            rc = apply_seq(q);
+            if (rc) return rc;
+            // (iv) all blocks in parallel from their boundary states, into the caller's storage
+            if (store) {
+                KrSweepArgs r = a;
+                r.tb_NT = h->cfg.NT; r.tb_S = h->tb_S; r.tb_bound = h->tb_bound_d; r.tb_items = h->tb_items_d; r.tb_nitems = h->tb_nitems;
+                HIPCHK(h, kr_launch_tblock(1, h->tb_NB * h->tb_nitems, h->stream, &r, nullptr));
             }
         }
-        a.gen_div = h->KT * h->sets / kt_apply;   // apply tiles per update tile (wg_gen is indexed by update tile)
-        if (a.gen_div < 1) a.gen_div = 1;
-        HIPCHK(h, h->launch(h->LMAXv, kt_apply, 3, h->Kp / (h->SG * kt_apply), h->stream, &a));
     } else {
         const int kt_known = std::min(h->KT, 4);   // (KT = 8 exists only for the matrix-core update sweep)
         a.gen_div = h->KT * h->sets / kt_known;
@@ -1907,6 +2093,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     a.init = h->psi0_d; a.store = h->store_fw ? h->Phi_d : nullptr; a.fin = h->psiT_d;
     a.X = h->X_d; a.alpha = h->S_d; a.eps_new = eps_new_dev; a.g_a_int = h->gint_d;
     a.dir = +1;
+    a.coh = (h->pulse_check && !calib_steps && !h->rowsplit) ? h->mail_d + KR_MAIL_COH_OFF : nullptr;   // (zeroed with the mailbox, below)
     a.epoch_base = h->epoch_base;
     h->last_epoch_base = h->epoch_base;
     // next launch: first tag = last tag + 3 (odd step: buffer parity keeps alternating); 32-bit wrap-around is
@@ -1944,7 +2131,13 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
         }
     }
     h->tl_launch1 = now_ms();
-    return ev_mark(h, 2, true);
+    rc = ev_mark(h, 2, true);
+    if (rc) return rc;
+    if (a.coh) {   // every workgroup formed the same pulse in every step (outside the timed kernel, ~3 us)
+        hipLaunchKernelGGL(kr_pulse_check, dim3(1), dim3(256), 0, h->stream, a.coh, h->P, h->status_d);
+        HIPCHK(h, hipGetLastError());
+    }
+    return KR_OK;
 }
 
 // The exchange of the update sweep has two schedules (kr_exchange): wave 0 publishes and polls (its first pass then also
@@ -2037,6 +2230,11 @@ static int check_status(kr_handle *h) {
         if (st[1] == 7)
             return fail(h, KR_ERR_INTERNAL, "the %s generator pack on the device no longer matches the operators kr_create uploaded (checksum mismatch in front of a sweep): device memory was corrupted; results of this call are invalid -- create a new handle",
                         st[2] == 0 ? "forward" : st[2] == 1 ? "adjoint (backward-sweep)" : st[2] == 2 ? "dense (matrix-core)" : st[2] == 3 ? "column-major forward" : "column-major adjoint");
+        if (st[1] == 8)
+            return fail(h, KR_ERR_INTERNAL, "update sweep: workgroup %u formed other pulse values than workgroup 0 in at least one step (their coherence words differ: a partial sum of the per-step exchange was lost or accepted stale in one workgroup's gather); results of this call are invalid",
+                        st[2]);
+        if (st[1] == 9)
+            return fail(h, KR_ERR_INTERNAL, "mailbox self-test failed (workgroup %u, round %u): device memory of this process loses stores or hides them from some XCDs", st[2] & 0xffffu, (st[2] >> 16) & 0xffu);
         if (st[1] == 6)
             return fail(h, KR_ERR_INTERNAL, "row-split sweep: the %d workgroups that share trajectory tile %u ended the sweep with different copies of its state vector (an all-gather element was lost or accepted stale); results of this call are invalid",
                         h->R, st[2]);
@@ -2063,12 +2261,14 @@ static int check_status(kr_handle *h) {
         }
         if ((st[1] == 2 || st[1] == 1) && h->mail_d && !h->rowsplit && h->wg_stride == 1) {
             // ... and inside this GPU: how many of the P workgroups' partial sums of that step each replica of the mailbox holds
-            const int LM = h->LMAXv, lpar = (int)(st[2] & 1u);
-            const unsigned phase = ((st[2] >> 1) & 1u) ^ 1u;
+            // (layout: the packed slots of kr_exchange -- slot q at word q * LMAX of every replica, KR_SLOT_GRANULES; the one-XCD
+            //  placement with its one slot per 128-byte line is excluded above; buffer and phase by the kernel's own helpers)
+            const int LM = h->LMAXv, lpar = kr_mail_buffer(st[2]);
+            const unsigned phase = kr_mail_phase(st[2]);
             std::vector<unsigned long long> mb((size_t)KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE, 0ull);
             if (hipMemcpyAsync(mb.data(), h->mail_d + (size_t)lpar * KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE, mb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
                 hipStreamSynchronize(h->stream) == hipSuccess) {
-                seen += "; partial sums of that step in the mailbox replicas:";
+                seen += "; partial sums of that step in the mailbox replicas (slot stride " + std::to_string(LM) + " words):";
                 char b[48];
                 for (int r = 0; r < KR_MAIL_REPLICAS; ++r) {
                     int cnt = 0;
@@ -2360,6 +2560,35 @@ extern "C" int kr_rccl_get_unique_id(void *id_out) {
     });
 }
 
+// Communicators are kept for the life of the process (round 5): destroying one makes RCCL free its device buffers, and a block that
+// lands on the address range of a freed uncached block loses stores -- handles with exchange = RCCL created and destroyed
+// in turn were exactly that pattern.  A handle returns its communicator to a process-wide cache keyed by (device, world, rank) -- or
+// by the device list --, the next handle of the same shape takes it from there and ignores its unique id.  All ranks must then make
+// the same choice, which they do when they create their handles in the same order (SPMD); KROTOV_HIP_RCCL_CACHE=0: ncclCommDestroy
+// as before.
+struct KrCommEntry { std::vector<int> key; ncclComm_t comm; bool in_use; };
+static std::mutex g_comm_mtx;
+static std::vector<KrCommEntry> g_comms;
+static ncclComm_t rccl_cache_take(const std::vector<int> &key) {
+    std::lock_guard<std::mutex> g(g_comm_mtx);
+    for (auto &e : g_comms) if (!e.in_use && e.key == key) { e.in_use = true; return e.comm; }
+    return nullptr;
+}
+static void rccl_cache_add(const std::vector<int> &key, ncclComm_t c) {
+    std::lock_guard<std::mutex> g(g_comm_mtx);
+    g_comms.push_back({key, c, true});
+}
+static bool rccl_cache_unuse(ncclComm_t c) {
+    std::lock_guard<std::mutex> g(g_comm_mtx);
+    for (auto &e : g_comms) if (e.comm == c) { e.in_use = false; return true; }
+    return false;
+}
+static void rccl_release(kr_handle *h) {
+    if (!h->rccl_comm) return;
+    if (!rccl_cache_unuse(h->rccl_comm) && kr_rccl()) (void)kr_rccl()->CommDestroy(h->rccl_comm);   // (not cached: KROTOV_HIP_RCCL_CACHE=0)
+    h->rccl_comm = nullptr;
+}
+
 static int one_rccl_init(kr_handle *h, const void *unique_id) {
     if (!h || !unique_id) return h ? fail(h, KR_ERR_INVALID, "kr_rccl_init: null") : KR_ERR_INVALID;
     std::lock_guard<std::mutex> g(h->mtx);
@@ -2367,10 +2596,14 @@ static int one_rccl_init(kr_handle *h, const void *unique_id) {
     if (!r) return fail(h, KR_ERR_UNSUPPORTED, "%s", kr_rccl_why());
     if (h->rccl_comm) return fail(h, KR_ERR_STATE, "kr_rccl_init: already initialised");
     HIPCHK(h, hipSetDevice(h->device));
+    const bool cache = opt_int(h, "RCCL_CACHE", 1) != 0;
+    const std::vector<int> key = {0, h->device, h->cfg.world, h->cfg.rank};
+    if (cache && (h->rccl_comm = rccl_cache_take(key)) != nullptr) return KR_OK;
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
     const ncclResult_t rc = r->CommInitRank(&h->rccl_comm, h->cfg.world, id, h->cfg.rank);
     if (rc != ncclSuccess) { h->rccl_comm = nullptr; return fail(h, KR_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString(rc)); }
+    if (cache) rccl_cache_add(key, h->rccl_comm);
     return KR_OK;
 }
 
@@ -2383,7 +2616,10 @@ static int one_set_exchange_callback(kr_handle *h, kr_allreduce_fn fn, void *ctx
 }
 
 // ---- multi-GPU mailbox wiring --------------------------------------------------------------------
-extern "C" int kr_ipc_handle_size(void) { return (int)sizeof(hipIpcMemHandle_t); }
+// What a rank exports (kr_ipc_handle_size() bytes, opaque to the caller): the IPC handle of its mailbox, how often its process has
+// handed that block out (special_alloc), and whether the block is pooled (never freed while the exporter lives).
+struct KrIpcBlob { hipIpcMemHandle_t mh; unsigned long long gen; unsigned pooled, pad; };
+extern "C" int kr_ipc_handle_size(void) { return (int)sizeof(KrIpcBlob); }
 
 static int one_ipc_export(kr_handle *h, void *handle_out) {
     if (!h || !handle_out) return h ? fail(h, KR_ERR_INVALID, "kr_ipc_export: null") : KR_ERR_INVALID;
@@ -2391,9 +2627,12 @@ static int one_ipc_export(kr_handle *h, void *handle_out) {
     if (h->cfg.world <= 1) return fail(h, KR_ERR_STATE, "kr_ipc_export: world = 1");
     if (h->gen_update) return fail(h, KR_ERR_STATE, "kr_ipc_export: this handle exchanges per step (RCCL / callback), it has no mailboxes to wire");
     HIPCHK(h, hipSetDevice(h->device));
-    hipIpcMemHandle_t mh;
-    HIPCHK(h, hipIpcGetMemHandle(&mh, h->xmail_d));
-    memcpy(handle_out, &mh, sizeof mh);
+    KrIpcBlob b;
+    memset(&b, 0, sizeof b);
+    HIPCHK(h, hipIpcGetMemHandle(&b.mh, h->xmail_d));
+    b.gen = h->xmail_gen;
+    b.pooled = opt_int(h, "UC_POOL", 1) != 0 ? 1u : 0u;
+    memcpy(handle_out, &b, sizeof b);
     return KR_OK;
 }
 
@@ -2402,10 +2641,13 @@ static int one_ipc_export(kr_handle *h, void *handle_out) {
 // blocks, so a later handle of the same peer presents the same IPC handle again and gets the mapping that is already there).
 static std::mutex g_ipc_mtx;
 static std::vector<std::tuple<int, hipIpcMemHandle_t, void *>> g_ipc_open;   // (device, handle, mapping)
-static hipError_t ipc_open(kr_handle *h, const hipIpcMemHandle_t &mh, void **p) {
-    if (opt_int(h, "UC_POOL", 1) == 0) { h->peers_cached = false; return hipIpcOpenMemHandle(p, mh, hipIpcMemLazyEnablePeerAccess); }
+// (a mapping is cached only when the EXPORTER keeps its block: the cache is keyed by the raw handle bytes, and a block that its
+//  owner really frees could come back under the same bytes with the old mapping pointing at released memory)
+static hipError_t ipc_open(kr_handle *h, const hipIpcMemHandle_t &mh, bool exporter_pooled, void **p, bool *cached) {
+    *cached = false;
+    if (opt_int(h, "UC_POOL", 1) == 0 || !exporter_pooled) return hipIpcOpenMemHandle(p, mh, hipIpcMemLazyEnablePeerAccess);
     std::lock_guard<std::mutex> g(g_ipc_mtx);
-    h->peers_cached = true;
+    *cached = true;
     for (auto &e : g_ipc_open)
         if (std::get<0>(e) == h->device && memcmp(&std::get<1>(e), &mh, sizeof mh) == 0) { *p = std::get<2>(e); return hipSuccess; }
     const hipError_t rc = hipIpcOpenMemHandle(p, mh, hipIpcMemLazyEnablePeerAccess);
@@ -2417,14 +2659,22 @@ static int one_ipc_connect(kr_handle *h, const void *all_handles) {
     std::lock_guard<std::mutex> g(h->mtx);
     if (h->cfg.world <= 1) return fail(h, KR_ERR_STATE, "kr_ipc_connect: world = 1");
     HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long mix = 0ull;
     for (int r = 0; r < h->cfg.world; ++r) {
+        KrIpcBlob b;
+        memcpy(&b, (const char *)all_handles + (size_t)r * sizeof b, sizeof b);
+        mix = mix * 1000003ull + b.gen;
         if (r == h->cfg.rank) continue;
-        hipIpcMemHandle_t mh;
-        memcpy(&mh, (const char *)all_handles + (size_t)r * sizeof mh, sizeof mh);
         void *p = nullptr;
-        HIPCHK(h, ipc_open(h, mh, &p));
+        bool cached = false;
+        HIPCHK(h, ipc_open(h, b.mh, b.pooled != 0, &p, &cached));
         h->peer_xmail[r] = (unsigned long long *)p;
+        h->peer_cached[r] = cached;
     }
+    // Tag base of this set of handles: every rank sees the same array, so every rank forms the same base -- and a set that recycles a
+    // pooled mailbox forms another one than the set that had it before (a late store of the earlier set cannot satisfy a poll).
+    h->epoch_base = (unsigned)((mix * 0x9E3779B97F4A7C15ull) >> 34);   // 30 bits: far from the 32-bit wrap
+    h->func_epoch = h->epoch_base;
     h->peers_connected = true;
     return KR_OK;
 }
@@ -2435,6 +2685,7 @@ static int one_ipc_connect(kr_handle *h, const void *all_handles) {
 // trajectories over P shard handles (rank i of world P, one per listed device), wires their exchange in-process (peer access
 // instead of IPC for the mailboxes; ncclCommInitAll for RCCL) and runs every call on all shards from P threads at once --
 // the update sweeps of the shards wait for each other inside their kernels, so they must be in flight together.
+static void group_quiesce(kr_handle *g);
 template <class F>
 static int group_run(kr_handle *g, F f) {
     const int P = (int)g->subs.size();
@@ -2456,6 +2707,8 @@ static int group_run(kr_handle *g, F f) {
     body(0);
     for (auto &t : th) t.join();
     for (int i = 0; i < P; ++i)
+        if (rcs[i] != KR_OK) { group_quiesce(g); break; }   // a failed call returns with every shard idle (asynchronous chain calls do not wait otherwise)
+    for (int i = 0; i < P; ++i)
         if (rcs[i] != KR_OK) {
             std::string tl;
             if (rcs[i] == KR_ERR_TIMEOUT) {   // who was late: every shard's host timeline of its last update sweep
@@ -2475,7 +2728,15 @@ static int group_run(kr_handle *g, F f) {
 static inline bool is_group(const kr_handle *h) { return h && !h->subs.empty(); }
 static inline size_t soff(const kr_handle *g, int i) { return (size_t)g->k_off[i] * g->cfg.N * 2; }   // doubles into a [K][N] complex array
 
+// Every shard's work has left its device.  The shards' persistent kernels store into EACH OTHER's mailboxes, so no shard's memory may
+// be released (and no failed call may return to a caller who will release it) while any sibling's kernel can still be running: a
+// sweep that timed out on one shard returns there at once, while a late sibling keeps spinning -- and storing -- up to its own bound.
+static void group_quiesce(kr_handle *g) {
+    for (kr_handle *s : g->subs)
+        if (s && s->stream) { (void)hipSetDevice(s->device); (void)hipStreamSynchronize(s->stream); }
+}
 static int group_destroy(kr_handle *g) {
+    group_quiesce(g);   // ALL streams first: one_destroy waits for its own shard's stream only
     for (kr_handle *s : g->subs) if (s) (void)one_destroy(s);
     delete g;
     return KR_OK;
@@ -2548,13 +2809,29 @@ static int group_create(const kr_config *cfg, kr_handle **out) {
             g->subs[i]->peers_connected = true;
             g->subs[i]->peers_in_process = true;
         }
+        {   // one tag base per group, another for every group this process creates (pooled mailboxes: see one_ipc_connect)
+            static std::mutex seq_mtx;
+            static unsigned seq = 0;
+            unsigned mine;
+            { std::lock_guard<std::mutex> lk(seq_mtx); mine = ++seq; }
+            const unsigned base = (unsigned)(((unsigned long long)mine * 0x9E3779B97F4A7C15ull) >> 34);
+            for (int i = 0; i < P; ++i) { g->subs[i]->epoch_base = base; g->subs[i]->func_epoch = base; }
+        }
     } else if (ex == KR_EXCHANGE_RCCL) {
         KrRccl *r = kr_rccl();
         if (!r) { fail(g, KR_ERR_UNSUPPORTED, "%s", kr_rccl_why()); return bail(KR_ERR_UNSUPPORTED); }
         for (int i = 0; i < P; ++i) if (share[i] > 1) { fail(g, KR_ERR_UNSUPPORTED, "exchange = RCCL needs distinct devices (device %d is listed %d times)", cfg->devices[i], share[i]); return bail(KR_ERR_UNSUPPORTED); }
         std::vector<ncclComm_t> comms(P, nullptr);
-        const ncclResult_t rc = r->CommInitAll(comms.data(), P, cfg->devices);
-        if (rc != ncclSuccess) { fail(g, KR_ERR_HIP, "ncclCommInitAll failed: %s", r->GetErrorString(rc)); return bail(KR_ERR_HIP); }
+        const bool cache = opt_int(g->subs[0], "RCCL_CACHE", 1) != 0;
+        auto key_of = [&](int i) { std::vector<int> k = {1, P, i}; for (int j = 0; j < P; ++j) k.push_back(cfg->devices[j]); return k; };
+        bool have = cache;
+        for (int i = 0; i < P && have; ++i) have = (comms[i] = rccl_cache_take(key_of(i))) != nullptr;
+        if (!have) {
+            for (int i = 0; i < P; ++i) if (comms[i]) { (void)rccl_cache_unuse(comms[i]); comms[i] = nullptr; }   // (a partial set goes back)
+            const ncclResult_t rc = r->CommInitAll(comms.data(), P, cfg->devices);
+            if (rc != ncclSuccess) { fail(g, KR_ERR_HIP, "ncclCommInitAll failed: %s", r->GetErrorString(rc)); return bail(KR_ERR_HIP); }
+            if (cache) for (int i = 0; i < P; ++i) rccl_cache_add(key_of(i), comms[i]);
+        }
         for (int i = 0; i < P; ++i) g->subs[i]->rccl_comm = comms[i];
     }
     } catch (...) {   // no half-built group (and none of its shards' device memory) survives an exception
