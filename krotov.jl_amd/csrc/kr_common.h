@@ -79,11 +79,12 @@ struct KrSweepArgs {
     // sc1 loads: 295 ns per hop against 626 ns across XCDs, profiles/r02_ubench_pingpong.txt).  Confirmed in the kernel from
     // HW_REG_XCC_ID; any other placement keeps the replicated write-through mailbox.  1 = ordinary launch.
     int wg_stride;
-    // Pulse coherence words (round 5; kr_sweep_update, kr_mf_update, kr_stream_update): every workgroup forms eps_new for ITSELF from the
-    // totals it gathered; one lane folds the values of all steps into a 64-bit word and posts it here when the sweep ends ([P] words
-    // behind the mailbox, zeroed with it); kr_pulse_check compares the P words after the launch (status code 8).  nullptr: not posted
-    // (calibration launches).  optimize.jl:351-358: ONE pulse value per step, whoever consumes it.
-    unsigned long long *coh;
+    // Log of the per-step totals (round 5; kr_sweep_update, kr_mf_update, kr_stream_update): every workgroup forms eps_new for ITSELF from
+    // the totals du_l it gathered; one lane of an otherwise idle wave stores them, dulog[(wg NT + n) LMAX + l].  After the sweep
+    // kr_pulse_finish forms the caller's eps_new from workgroup 0's log -- the kernels themselves no longer write it -- and compares all P
+    // logs bit for bit (status code 8): a workgroup that summed a stale or lost partial sum has propagated with another pulse than its
+    // neighbours.  optimize.jl:351-358: ONE pulse value per step, whoever consumes it.
+    double *dulog;
     // Known-pulse sweeps in blocks of time (round 5; kr_device_tblock.h, NP = 64): steps [b S, (b + 1) S) form block b; tb_bound holds
     // the state at every block boundary ([NB + 1][Kp][N], written by the sequential apply sweep over the block propagators),
     // tb_items the trajectory ranges one workgroup carries ({first slot, count <= 64, generator, 0} per item).
@@ -93,8 +94,6 @@ struct KrSweepArgs {
 };
 #define KR_MAIL_XTAB_OFF ((size_t)2 * KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE + 64 * 4)   // words: XCC-id table behind the mailbox + tail
 #define KR_MAIL_XTAB_WORDS 64
-#define KR_MAIL_COH_OFF (KR_MAIL_XTAB_OFF + KR_MAIL_XTAB_WORDS)   // words: pulse coherence words, one per workgroup (KrSweepArgs::coh)
-#define KR_MAIL_COH_WORDS 2048
 // buffer and validity phase of the mailbox inside the GPU at step n of a launch (kr_exchange; the timeout report of krotov_hip.hip
 // reads the mailbox with the same two expressions)
 __host__ __device__ inline int kr_mail_buffer(const unsigned n) { return (int)(n & 1u); }

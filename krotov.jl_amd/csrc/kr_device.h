@@ -166,19 +166,6 @@ __device__ __forceinline__ KrEcon kr_econ_select(const double ec, const double t
 
 __device__ __forceinline__ unsigned long long kr_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 
-// Pulse coherence word of a workgroup (KrSweepArgs::coh): two 32-bit halves, each rotated and mixed with one half of the new value --
-// five full-rate vector instructions per pulse value on every lane, no branch, no scalar registers (the first version kept the word in
-// scalar registers: the update kernels sit at the SGPR limit, and the extra spills to vector lanes cost C3 3 % -- 5.18 -> 5.33 us per
-// step, same-box A/B).  Order-sensitive; every bit of every value counts.  `fault`: the planted fault of the tests (option PULSE_FAULT).
-struct KrPulseFold { unsigned a, b; };
-__device__ __forceinline__ void kr_pulse_fold_v(KrPulseFold &f, const double v, const bool fault = false) {
-    const unsigned lo = (unsigned)__double2loint(v) ^ (fault ? 1u : 0u), hi = (unsigned)__double2hiint(v);
-    const unsigned ra = __builtin_amdgcn_alignbit(f.a, f.a, 19), rb = __builtin_amdgcn_alignbit(f.b, f.b, 25);   // rotate left by 13 / 7
-    f.a = (ra ^ lo) + f.b;
-    f.b = rb ^ hi;
-}
-__device__ __forceinline__ unsigned long long kr_pulse_word(const KrPulseFold &f) { return (((unsigned long long)f.b << 32) | f.a) | (1ull << 63); }
-
 typedef __attribute__((address_space(1))) unsigned long long kr_gu64;
 typedef __attribute__((address_space(1))) unsigned kr_gu32;
 
@@ -887,7 +874,6 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     __shared__ __attribute__((aligned(16))) double2 sc[2][KTILE][NPP];  // chi(t_k) in slot k & 1, padded like sx (it is a matvec operand when HERM)
     __shared__ double spart[LMAX * 64];
     __shared__ double stot[LMAX + 1];
-
     // one-XCD placement of a small grid (KrSweepArgs::wg_stride): only every wg_stride-th block works
     const int wstride = (XLOC && a.wg_stride > 1) ? a.wg_stride : 1;
     if (XLOC && wstride > 1 && (blockIdx.x % wstride) != 0) return;
@@ -1018,7 +1004,14 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     }
     const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
     double ec_nx = econ_rows ? econ_rows[0] : 0.0;
-    KrPulseFold pfold = {0u, 0u};   // coherence word: every pulse value this workgroup formed, folded in step order
+    // This workgroup's log of the totals it gathers (KrSweepArgs::dulog; kr_pulse_finish forms eps_new from workgroup 0's and compares
+    // all of them).  Stored behind the exchange by lane 0 of wave 2, which issues no other vector-memory operation.  Measured, C3 / C2
+    // update sweep against the kernel without any of it (5.21 / 3.23 us per step, same box, profiles/r05_ab_guard.log): this form 5.29 /
+    // 3.19; the totals parked in LDS and stored at the top of the next step 5.35 / 3.27, by the memory wave next to its storage writes
+    // 5.33 / 3.29, through a 64-step ring in LDS with one coalesced store per 64 steps 5.24 / 3.35; a fold of the pulse values kept in
+    // two VGPRs 5.35 / 3.27, in scalar registers 5.33, in LDS 5.37 / 3.32; every workgroup's memory wave writing its own copy of eps_new
+    // 5.44 / 3.28.  The kernel's speed hangs on its register allocation and on which wave reaches a barrier last, not on the work added.
+    double *const dulog = a.dulog + (size_t)wg * NT * LMAX;
     for (int n = 0; n < NT; ++n) {
         const double dt = dt_nx;
         const double ec = ec_nx;
@@ -1133,6 +1126,10 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         // ---- global sum over all trajectories of all workgroups (and GPUs) ------------------
         double du[LMAX];
         if (!kr_exchange<LMAX, 64, SCHED>(a, n, wg, writer, rowid, part, du, spart, stot, window, XLOC ? xlocal : false, HERM && n > 0)) return;
+        if (tid == 128) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) dulog[(size_t)n * LMAX + l] = (l == 0 && a.rs_fault == 2 && wg == 1 && n == 3) ? -du[l] : du[l];   // (rs_fault 2: the planted fault of the tests)
+        }
 
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 
@@ -1173,8 +1170,6 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 const double ad = fabs(du[l]);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dt));
                 theta += fabs(e[l]) * gx.nrm[1 + l];
-                if (wg == 0 && memwave && lane == 0) a.eps_new[(size_t)l * NT + n] = e[l];
-                kr_pulse_fold_v(pfold, e[l], a.rs_fault == 2 && wg == 1 && n == 3);
             }
         }
         theta *= fabs(dt);
@@ -1294,7 +1289,6 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
     }
-    if (a.coh && tid == 0) a.coh[wg] = kr_pulse_word(pfold);   // (bit 63: a workgroup that never got here leaves the zero of the launch's memset)
 }
 
 // ---- launcher table for one NP ---------------------------------------------------------------

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     }
     const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
     double ec_nx = econ_rows ? econ_rows[0] : 0.0;
-    KrPulseFold pfold = {0u, 0u};   // coherence word (kr_device.h: kr_pulse_fold_v)
+    double *const dulog = a.dulog + (size_t)wg * NT * LMAX;   // (kr_sweep_update, kr_device.h)
     for (int n = 0; n < NT; ++n) {
         const double dtn = dt_nx;
         const double ec = ec_nx;
@@ -369,6 +369,10 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         // ---- global sum over all trajectories of all workgroups (and GPUs): one value per wave goes in ----
         double du[LMAX];
         if (!kr_exchange<LMAX, NW, SCHED>(a, n, wg, lane == 0, wave, part, du, spart, stot, window)) return;
+        if (tid == 128) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) dulog[(size_t)n * LMAX + l] = (l == 0 && a.rs_fault == 2 && wg == 1 && n == 3) ? -du[l] : du[l];
+        }
         if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tX += t - t_prev; t_prev = t; }
 
         // ---- pulse update (optimize.jl:351-358), identical on every workgroup ----
@@ -383,8 +387,6 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
                 const double ad = fabs(du[l]);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dtn));
                 theta += fabs(e[l]) * gx.nrm[1 + l];
-                if (wg == 0 && memwave && lane == 0) a.eps_new[(size_t)l * NT + n] = e[l];
-                kr_pulse_fold_v(pfold, e[l], a.rs_fault == 2 && wg == 1 && n == 3);
             }
         }
         theta *= fabs(dtn);
@@ -516,7 +518,6 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
     }
-    if (a.coh && tid == 0) a.coh[wg] = kr_pulse_word(pfold);
 #undef KR_SX_RD
 #undef KR_SX_WR
 #undef KR_SC_AT

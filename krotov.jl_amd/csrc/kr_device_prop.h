@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
     const double fs = ldexp(sdt, -q);
 
     // A fragments: A = -i fs H  ->  Ar = fs Hi,  Ai = -fs Hr  (row 16w + li, column 4t + lk)
-    double Ar[16], Ai[16], nAi[16];
+    double Ar[16], Ai[16];
     const int row = 16 * w + li;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -312,7 +312,6 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
         }
         Ar[t] = fs * hi;
         Ai[t] = -fs * hr;
-        nAi[t] = fs * hr;
     }
     int cur = 0;
     // ---- Paterson-Stockmeyer evaluation for 5 <= m <= 7 (round 3): p(A) = B0 + B1 A^4, Bk = c_4k + c_4k+1 A + c_4k+2 A^2 + c_4k+3 A^3
@@ -331,7 +330,12 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
 #pragma unroll
         for (int j = 2; j < 8; ++j) c[j] = (j <= m) ? c[j - 1] * kr_rinv_lane(my_g, j) : 0.0;
         // one product: (Lr + i Li) x (buffer b)  ->  sink(ct, re[4], im[4]) per column tile, D layout (row 16 w + lk + 4 r, column 16 ct + li)
+        // (round 5: THREE real products per complex one -- re = Lr Br - Li Bi, im = (Lr + Li)(Br + Bi) - Lr Br - Li Bi --, the operand
+        //  sums are vector adds in the shadow of the matrix cores: a quarter fewer MFMAs, which bound this kernel)
         auto product = [&](const double (&Lr)[16], const double (&Li)[16], const int b, auto sink) {
+            double Ls[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Ls[t] = Lr[t] + Li[t];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 kr_d4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0}, pc = {0, 0, 0, 0};
@@ -339,12 +343,12 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
                 for (int t = 0; t < 16; ++t) {
                     const double br = KR_YR(b)[(4 * t + lk) * KR_YS + 16 * ct + li];
                     const double bi = KR_YI(b)[(4 * t + lk) * KR_YS + 16 * ct + li];
+                    const double bs = br + bi;
                     pa = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[t], br, pa, 0, 0, 0);
                     pb = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[t], bi, pb, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[t], bi, pc, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[t], br, pc, 0, 0, 0);
+                    pc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[t], bs, pc, 0, 0, 0);
                 }
-                sink(ct, pa - pb, pc);
+                sink(ct, pa - pb, (pc - pa) - pb);
             }
         };
         auto store_d = [&](const int b, const int ct, const kr_d4 vr, const kr_d4 vi) {
@@ -432,21 +436,25 @@ __global__ __launch_bounds__(256, 1) void kr_expm_mfma64(const KrSweepArgs a) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const double yr = KR_YR(cur)[row * KR_YS + 4 * t + lk], yi = KR_YI(cur)[row * KR_YS + 4 * t + lk];
-                Ar[t] = yr; Ai[t] = yi; nAi[t] = -yi;
+                Ar[t] = yr; Ai[t] = yi;
             }
         }
+        double As[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) As[t] = Ar[t] + Ai[t];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            kr_d4 cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+            kr_d4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0}, pc = {0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const double br = KR_YR(cur)[(4 * t + lk) * KR_YS + 16 * ct + li];
                 const double bi = KR_YI(cur)[(4 * t + lk) * KR_YS + 16 * ct + li];
-                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[t], br, cr, 0, 0, 0);
-                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(nAi[t], bi, cr, 0, 0, 0);
-                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[t], bi, ci, 0, 0, 0);
-                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[t], br, ci, 0, 0, 0);
+                const double bs = br + bi;
+                pa = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[t], br, pa, 0, 0, 0);
+                pb = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[t], bi, pb, 0, 0, 0);
+                pc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[t], bs, pc, 0, 0, 0);
             }
+            const kr_d4 cr = pa - pb, ci = (pc - pa) - pb;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int orow = 16 * w + lk + 4 * r, ocol = 16 * ct + li;

@@ -220,7 +220,7 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
     for (int l = 0; l < LMAX; ++l) gint[l] = 0.0;
     __syncthreads();
     int cur = 0;
-    KrPulseFold pfold = {0u, 0u};   // coherence word (kr_device.h: kr_pulse_fold_v)
+    double *const dulog = a.dulog + (size_t)wg * NT * LMAX;   // (kr_sweep_update, kr_device.h)
     for (int n = 0; n < NT; ++n) {
         const double dt = a.dt[n];
         const double ec = econ_rows ? econ_rows[(size_t)n * KR_ECON_W] : 0.0;
@@ -254,6 +254,10 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
         }
         double du[LMAX];
         if (!kr_exchange<LMAX, ROWS>(a, n, wg, writer, i, part, du, spart, stot)) return;
+        if (tid == 128) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) dulog[(size_t)n * LMAX + l] = (l == 0 && a.rs_fault == 2 && wg == 1 && n == 3) ? -du[l] : du[l];
+        }
 
         double e[LMAX], de[LMAX];
         double theta = gx.nrm[0];
@@ -267,8 +271,6 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
                 const double ad = fabs(du[l]);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(al[l], __dmul_rn(ad, ad)), dt));
                 theta += fabs(e[l]) * gx.nrm[1 + l];
-                if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = e[l];
-                kr_pulse_fold_v(pfold, e[l], a.rs_fault == 2 && wg == 1 && n == 3);
             }
         }
         theta *= fabs(dt);
@@ -353,7 +355,6 @@ __global__ __launch_bounds__((KrGeomS<NP, LMAX, KT>::THREADS)) void kr_stream_up
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) if (l < L) a.g_a_int[l] = gint[l];
     }
-    if (a.coh && tid == 0) a.coh[wg] = kr_pulse_word(pfold);
 }
 
 template <int NP>

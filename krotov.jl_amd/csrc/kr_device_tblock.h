@@ -20,9 +20,9 @@
 // therefore holds rows 4 (4 w' + r) + (l >> 4) -- EXACTLY the B operand of k-block t = 4 w' + r.  A wave that computes all four row tiles
 // of its 16 columns holds the new state as the next step's B operands: the state never leaves the registers, the waves of a workgroup
 // share nothing but the LDS copy of U_s and meet once per step.  Columns = trajectories; real and imaginary parts are separate operand
-// sets (y_r = U_r x_r - U_i x_i, y_i = U_r x_i + U_i x_r: four real products per k-block, four independent accumulator chains).
-// A wave carries 16 trajectories, a workgroup 64; U_s (64 KB as {U_r, U_i} fragment pairs) is copied global -> LDS by LDS-DMA one step
-// ahead (two buffers); per step and wave 256 MFMAs (16.4 k cycles at the fp64 matrix rate) against 64 ds_read_b128.
+// sets (y_r = U_r x_r - U_i x_i, y_i = (U_r + U_i)(x_r + x_i) - U_r x_r - U_i x_i: three real products per k-block, three independent
+// accumulator chains).  A wave carries 16 trajectories, a workgroup 64; U_s (64 KB as {U_r, U_i} fragment pairs) is copied global -> LDS
+// by LDS-DMA one step ahead (two buffers); per step and wave 192 MFMAs (12.3 k cycles at the fp64 matrix rate) against 64 ds_read_b128.
 #pragma once
 #include "kr_common.h"
 
@@ -62,27 +62,30 @@ __global__ __launch_bounds__(256, 1) void kr_tb_products(const KrSweepArgs a, do
     __syncthreads();
     int cur = 0;
     for (int s = s0 + 1; s < s1; ++s) {
-        double Ar[16], Ai[16];
+        // complex product in THREE real ones (round 5):  re = Ar Br - Ai Bi,  im = (Ar + Ai)(Br + Bi) - Ar Br - Ai Bi.  The sums of the
+        // operands are vector adds in the shadow of the matrix cores; a quarter of the MFMAs -- which bound these kernels -- is saved,
+        // at the price of one more rounding of the imaginary part's operands (errors stay ~1e-16 of the matrices' size).
+        double Ar[16], Ai[16], As[16];
         const double2 *F = frag_of(s);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) { const double2 u = F[(size_t)t * 64]; Ar[t] = u.x; Ai[t] = u.y; }
+        for (int t = 0; t < 16; ++t) { const double2 u = F[(size_t)t * 64]; Ar[t] = u.x; Ai[t] = u.y; As[t] = u.x + u.y; }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            kr_tb_d4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0}, pc = {0, 0, 0, 0}, pd = {0, 0, 0, 0};
+            kr_tb_d4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0}, pc = {0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const double br = KR_TBR(cur)[(4 * t + lk) * KR_TB_YS + 16 * ct + li];
                 const double bi = KR_TBI(cur)[(4 * t + lk) * KR_TB_YS + 16 * ct + li];
+                const double bs = br + bi;
                 pa = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[t], br, pa, 0, 0, 0);
                 pb = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[t], bi, pb, 0, 0, 0);
-                pc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[t], bi, pc, 0, 0, 0);
-                pd = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[t], br, pd, 0, 0, 0);
+                pc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[t], bs, pc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int orow = 16 * w + lk + 4 * r, ocol = 16 * ct + li;
                 KR_TBR(cur ^ 1)[orow * KR_TB_YS + ocol] = pa[r] - pb[r];
-                KR_TBI(cur ^ 1)[orow * KR_TB_YS + ocol] = pc[r] + pd[r];
+                KR_TBI(cur ^ 1)[orow * KR_TB_YS + ocol] = (pc[r] - pa[r]) - pb[r];
             }
         }
         __syncthreads();
@@ -164,46 +167,50 @@ __global__ __launch_bounds__(256, 1) void kr_tb_apply(const KrSweepArgs a) {
         }
     };
     if (s0 < s_end) issue_u(0, s0);
-    if (a.store && b == 0) store_state(0);   // slot of the initial states
     for (int s = s0; s < s_end; ++s) {
         const int buf = (s - s0) & 1;
-        // U_s has landed (this wave's pieces: vmcnt; everybody's: the barrier), and every wave is done with the other buffer
+        // U_s has landed (this wave's pieces: vmcnt; everybody's: the barrier), and every wave is done with the other buffer.  The only
+        // other vector-memory operations in flight are the stores of the state below, issued a whole step (~7 us) ago.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (s + 1 < s_end) issue_u(buf ^ 1, s + 1);
+        // the state after s steps goes to its slot while the next one is computed (block b > 0: its first state is block b - 1's last)
+        if (a.store && (s > s0 || b == 0)) store_state(s);
         const double2 *Ul = kr_tba_lds + (size_t)buf * 4096 + lane;
         double yr[16], yi[16];
-        double2 ua[16];
+        // 64 operand pairs {U_r, U_i} (one ds_read_b128 each) feed 256 MFMAs through a window of eight registers pairs: pair q + 8 is
+        // requested right behind the MFMAs of pair q, i.e. every read rides on 8 x 256 cycles of matrix-core work (left to itself hipcc
+        // puts each read directly in front of its MFMAs and waits for it; sched_group_barrier did not move it either)
+        double2 win[8];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) ua[t] = Ul[(size_t)t * 64];
+        for (int q = 0; q < 8; ++q) win[q] = Ul[(size_t)q * 64];
+        // y = U x in THREE real products per k-block (see kr_tb_products): y_r = U_r x_r - U_i x_i, y_i = (U_r + U_i)(x_r + x_i) - U_r x_r - U_i x_i
+        double xs[16];
 #pragma unroll
-        for (int wt = 0; wt < 4; ++wt) {
-            double2 ub[16];
-            if (wt + 1 < 4) {
+        for (int t = 0; t < 16; ++t) xs[t] = xr[t] + xi[t];
+        kr_tb_d4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0}, pc = {0, 0, 0, 0};
 #pragma unroll
-                for (int t = 0; t < 16; ++t) ub[t] = Ul[(size_t)(16 * (wt + 1) + t) * 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);   // (the next row tile's operands are requested BEFORE this tile's MFMAs)
-            kr_tb_d4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0}, pc = {0, 0, 0, 0}, pd = {0, 0, 0, 0};
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                pa = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[t].x, xr[t], pa, 0, 0, 0);
-                pb = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[t].y, xi[t], pb, 0, 0, 0);
-                pc = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[t].x, xi[t], pc, 0, 0, 0);
-                pd = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[t].y, xr[t], pd, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { yr[4 * wt + r] = pa[r] - pb[r]; yi[4 * wt + r] = pc[r] + pd[r]; }
+        for (int q = 0; q < 64; ++q) {
+            const int t = q & 15, wt = q >> 4;
+            const double2 u = win[q & 7];
+            const double us = u.x + u.y;
             __builtin_amdgcn_sched_barrier(0);
-            if (wt + 1 < 4) {
+            pa = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, xr[t], pa, 0, 0, 0);
+            pb = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, xi[t], pb, 0, 0, 0);
+            pc = __builtin_amdgcn_mfma_f64_16x16x4f64(us, xs[t], pc, 0, 0, 0);
+            if (q + 8 < 64) win[q & 7] = Ul[(size_t)(q + 8) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 15) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) ua[t] = ub[t];
+                for (int r = 0; r < 4; ++r) { yr[4 * wt + r] = pa[r] - pb[r]; yi[4 * wt + r] = (pc[r] - pa[r]) - pb[r]; }
+                pa = kr_tb_d4{0, 0, 0, 0}; pb = kr_tb_d4{0, 0, 0, 0}; pc = kr_tb_d4{0, 0, 0, 0};
             }
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) { xr[t] = yr[t]; xi[t] = yi[t]; }
-        if (a.store) store_state(s + 1);
     }
+    if (a.store && s_end > s0) store_state(s_end);
+    else if (a.store && b == 0 && s_end == s0) store_state(0);
     if (a.store && b == NB - 1 && kok) {   // final states of the sweep: the sequential sweep's, bit for bit
         const double2 *src = a.tb_bound + (size_t)NB * slab + (size_t)kk * N;
         double2 *dst = a.store + (size_t)slot_of(NT) * slab + (size_t)kk * N;

@@ -115,7 +115,8 @@ struct kr_handle {
     size_t xmail_bytes = 0;
     unsigned last_epoch_base = 0;   // tag base of the last update launch (the timeout report prints the tags it expected)
     unsigned long long xmail_gen = 0;   // how often this process has handed out the xmail block (special_alloc): seeds the tag base of the handle
-    bool pulse_check = true;        // pulse coherence words compared after every update sweep of the N <= 64 / streamed kernels (kr_pulse_check)
+    bool pulse_check = true;        // the workgroups' logs of the per-step totals compared after every update sweep of the N <= 64 / streamed kernels (kr_pulse_finish)
+    double *dulog_d = nullptr;      // [P][NT][LMAX] (KrSweepArgs::dulog)
     int quarantined = 0;            // mailbox blocks that failed the self-test of kr_create and were set aside
     bool peers_connected = false;
     bool peers_in_process = false;   // peer mailboxes are plain pointers of sibling shards (device list), not IPC mappings
@@ -458,16 +459,24 @@ __global__ void kr_rowsplit_check(const unsigned long long *words, int tiles, in
     if (bad && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 6u; status[2] = (unsigned)t; }
 }
 
-// After an update sweep of the register-resident / matrix-core / streamed kernels (N <= 64 and the streamed fallback): every workgroup
-// formed eps_new for itself from the totals IT gathered and folded all N_T x L values into one word (KrSweepArgs::coh); the P words must
-// be equal -- a workgroup that summed a stale or lost partial sum once has propagated with another pulse than its neighbours
-// (status code 8).  optimize.jl:351-358 has ONE pulse value per step.
-__global__ __launch_bounds__(256) void kr_pulse_check(const unsigned long long *words, int P, unsigned *status) {
-    const unsigned long long ref = words[0];
-    bool bad = (ref >> 63) == 0ull;
+// Behind an update sweep of the register-resident / matrix-core / streamed kernels (N <= 64 and the streamed fallback).  Every
+// workgroup formed eps_new for itself from the totals du_l IT gathered and logged them (KrSweepArgs::dulog, [P][NT][LMAX]); the
+// kernels no longer write eps_new.  This kernel forms it from workgroup 0's log with the sweep's own expression (optimize.jl:354:
+// eps + (S / lambda) du, one rounded product, one rounded sum) and compares all P logs bit for bit: a workgroup that summed a
+// stale or lost partial sum once has propagated with another pulse than its neighbours (status code 8, with workgroup, control and
+// step).  optimize.jl:351-358 has ONE pulse value per step.
+__global__ __launch_bounds__(256) void kr_pulse_finish(const double *eps_guess, const double *alpha, const double *dulog, double *eps_new, int P, int L, int LMAX, int NT,
+                                                       int check, unsigned *status) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)L * NT) return;
+    const int l = (int)(i / NT), n = (int)(i % NT);
+    const double du = dulog[(size_t)n * LMAX + l];
+    eps_new[i] = __dadd_rn(eps_guess[i], __dmul_rn(alpha[i], du));
+    if (!check) return;
+    const long long ref = __double_as_longlong(du);
     int who = 0;
-    for (int q = threadIdx.x; q < P; q += 256) if (words[q] != ref) { bad = true; who = q; }
-    if (bad && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 8u; status[2] = (unsigned)who; }
+    for (int w = 1; w < P; ++w) if (__double_as_longlong(dulog[((size_t)w * NT + n) * LMAX + l]) != ref && who == 0) who = w;
+    if (who && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 8u; status[2] = (unsigned)who; status[3] = (unsigned)i; }
 }
 
 // Self-test of a freshly allocated mailbox (kr_create; round 5): the exchange pattern of the sweeps on the mailbox's own words -- every
@@ -971,7 +980,7 @@ static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->pack_words_d, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d, h->skw_d,
                     h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d,
-                    h->tb_P_d, h->tb_bound_d, h->tb_items_d};
+                    h->tb_P_d, h->tb_bound_d, h->tb_items_d, h->dulog_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected && !h->peers_in_process)   // (cached mappings stay open: ipc_open)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -1066,7 +1075,10 @@ static int mailbox_selftest(kr_handle *h, unsigned long long *base, int P, int r
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(st, h->status_d, sizeof st, hipMemcpyDeviceToHost, h->own_stream));
     HIPCHK(h, hipStreamSynchronize(h->own_stream));
-    if (st[0] != 0) HIPCHK(h, hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
+    if (st[0] != 0) {
+        HIPCHK(h, hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->own_stream));
+        HIPCHK(h, hipStreamSynchronize(h->own_stream));
+    }
     return KR_OK;
 }
 
@@ -1157,7 +1169,8 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     CHK(dalloc(&h->status_d, KR_STATUS_WORDS));
-    CHK(hipMemset(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned)));
+    CHK(hipMemsetAsync(h->status_d, 0, KR_STATUS_WORDS * sizeof(unsigned), h->own_stream));   // (own stream: the self-test kernels of kr_create run there)
+    CHK(hipStreamSynchronize(h->own_stream));
 
     const int N = cfg->N, NT = cfg->NT, L = cfg->L, NP = h->NP;
     const size_t nn = (size_t)N * N;
@@ -1368,7 +1381,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         //  groups with sets or turns -- not by the trajectory count, which differs from it with sets / turns / batches)
         h->xcd_group = ((h->P / h->R) % 8 == 0) && opt_int(h, "XCD_GROUP", 1) != 0;
         CHK(dalloc(&h->gmail_d, h->gmail_words));
-        CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
+        CHK(hipMemsetAsync(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long), h->own_stream)); CHK(hipStreamSynchronize(h->own_stream));
         if (opt_int(h, "MAIL_SELFTEST", 1) != 0) {   // the all-gather's mailbox: P words spread over the whole block
             unsigned st[KR_STATUS_WORDS] = {};
             rc = mailbox_selftest(h, h->gmail_d, h->P, 1, 0, (int)std::max<size_t>(1, h->gmail_words / (size_t)h->P), 1, 0, st);
@@ -1379,7 +1392,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
                      "device memory of this process loses stores or hides them from some XCDs; the block is set aside -- call kr_create again", st[2] & 0xffffu);
                 return bail(KR_ERR_INTERNAL);
             }
-            CHK(hipMemset(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long)));
+            CHK(hipMemsetAsync(h->gmail_d, 0, h->gmail_words * sizeof(unsigned long long), h->own_stream)); CHK(hipStreamSynchronize(h->own_stream));
         }
         if (h->rs_sets > 1) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * 4 /* KR_PAIR_MAX_SETS */ * 2 * NP));
         if (h->rs_turns > 0) CHK(dalloc(&h->rs_scratch_d, (size_t)h->P * KR_RS_MAX_TURNS * NP));
@@ -1441,19 +1454,22 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     CHK(hipMemset(h->psiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->chiT_d, 0, slab * sizeof(double2)));
     CHK(hipMemset(h->gint_d, 0, std::max(L, KR_LMAX_CAP) * sizeof(double)));
-    h->mail_words = KR_MAIL_COH_OFF + KR_MAIL_COH_WORDS;    // 2 buffers x 8 replicas (one per XCD) x 64 KB (kr_exchange); tail: a poll pass
+    h->mail_words = KR_MAIL_XTAB_OFF + KR_MAIL_XTAB_WORDS;  // 2 buffers x 8 replicas (one per XCD) x 64 KB (kr_exchange); tail: a poll pass
                                                             // reads whole 64-slot chunks (kr_poll_pass); then the XCC-id table of the
                                                             // one-XCD placement (kr_sweep_update)
     // (the generic update kernels do not use this mailbox: any number of tiles -- N = 8, K = 8193 used to fail here)
     if (!h->gen_update && (size_t)h->P * 4 > KR_MAIL_RSTRIDE) { fail(h, KR_ERR_UNSUPPORTED, "%d workgroups do not fit one mailbox replica", h->P); return bail(KR_ERR_UNSUPPORTED); }
-    h->pulse_check = opt_int(h, "PULSE_CHECK", 1) != 0 && (size_t)h->P <= KR_MAIL_COH_WORDS;
+    h->pulse_check = opt_int(h, "PULSE_CHECK", 1) != 0 && !h->gen_update && !h->rowsplit && h->P > 1;
+    if (!h->gen_update && !h->rowsplit) CHK(dalloc(&h->dulog_d, (size_t)h->P * NT * h->LMAXv));   // (eps_new is formed from workgroup 0's log whether the logs are compared or not)
     // The mailbox of the per-step exchange, self-tested (kr_mail_selftest: the exchange's own store / poll pattern on both buffers and
     // all replicas, ~50 us): a block on which stores get lost or stay invisible to some XCDs -- seen for blocks that reuse the address
     // range of a freed uncached block, which this library no longer frees but another library of the process may -- is set aside and
     // another one is asked for (three attempts; KROTOV_HIP_MAIL_SELFTEST=0 skips the test).
+    // (every memset of a mailbox under test runs on the handle's OWN stream and is waited for: the stream is non-blocking, a memset on
+    //  the null stream is not ordered with the self-test kernel and wiped words it had just published -- 18 false alarms in 243 tests)
     for (int attempt = 0;; ++attempt) {
         CHK(alloc_mailbox(h, &h->mail_d, h->mail_words, h->P));
-        CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long)));
+        CHK(hipMemsetAsync(h->mail_d, 0, h->mail_words * sizeof(unsigned long long), h->own_stream)); CHK(hipStreamSynchronize(h->own_stream));
         if (h->gen_update || opt_int(h, "MAIL_SELFTEST", 1) == 0) break;
         const int mf = opt_int(h, "MAIL_FAULT", 0);   // (tests: 1 = the first block fails, 2 = every block fails)
         unsigned st[KR_STATUS_WORDS] = {};
@@ -1462,7 +1478,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
                                   std::max(1, std::min(h->cfg.L, 4)), (mf == 2 || (mf == 1 && attempt == 0)) ? 1 : 0, st);
             if (rc != KR_OK) return bail(rc);
         }
-        if (st[0] == 0) { CHK(hipMemset(h->mail_d, 0, h->mail_words * sizeof(unsigned long long))); break; }
+        if (st[0] == 0) { CHK(hipMemsetAsync(h->mail_d, 0, h->mail_words * sizeof(unsigned long long), h->own_stream)); CHK(hipStreamSynchronize(h->own_stream)); break; }
         quarantine_block(h->mail_d);   // never used, never freed
         h->mail_d = nullptr;
         h->quarantined++;
@@ -1488,7 +1504,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
             h->xmail_d = nullptr;
         }
         if (!h->xmail_d) { fail(h, KR_ERR_HIP, "no device memory for the mailbox between GPUs"); return bail(KR_ERR_HIP); }
-        CHK(hipMemset(h->xmail_d, 0, xwords * sizeof(unsigned long long)));
+        CHK(hipMemsetAsync(h->xmail_d, 0, xwords * sizeof(unsigned long long), h->own_stream)); CHK(hipStreamSynchronize(h->own_stream));
         if (opt_int(h, "MAIL_SELFTEST", 1) != 0) {   // the mailbox between GPUs, as this GPU's workgroups see it
             unsigned st[KR_STATUS_WORDS] = {};
             rc = mailbox_selftest(h, h->xmail_d, 8, 1, 0, (int)(xwords / 8), 4, 0, st);
@@ -1498,7 +1514,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
                 fail(h, KR_ERR_INTERNAL, "kr_create: the mailbox between GPUs failed its self-test (workgroup %u did not see every published word within 20 ms); the block is set aside -- call kr_create again", st[2] & 0xffffu);
                 return bail(KR_ERR_INTERNAL);
             }
-            CHK(hipMemset(h->xmail_d, 0, xwords * sizeof(unsigned long long)));
+            CHK(hipMemsetAsync(h->xmail_d, 0, xwords * sizeof(unsigned long long), h->own_stream)); CHK(hipStreamSynchronize(h->own_stream));
         }
         h->peer_xmail[cfg->rank] = h->xmail_d;
     }
@@ -1517,10 +1533,10 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         static const char *const exn[] = {"auto", "mailbox", "rccl", "callback"};
         snprintf(buf, sizeof buf, "N=%d (padded %d) NT=%d K=%d (padded %d) L=%d G=%d rank %d/%d on device %d: update sweep = %s, %d workgroups x %d "
                  "trajectories, sets per workgroup %d, one-XCD placement %d, R=%d, HERM=%d, economized=%d, poll_delay=%d; known-pulse sweeps = %s; exchange = %s; spin bound %.0f ms; "
-                 "integrity checks: operator-copy checksums %s, group coherence words %s, pulse coherence words %s, mailbox self-test %s%s%s%s",
+                 "integrity checks: operator-copy checksums %s, group coherence words %s, per-step totals of all workgroups compared %s, mailbox self-test %s%s%s%s",
                  h->cfg.N, h->NP, h->cfg.NT, h->cfg.K, h->Kp, h->cfg.L, h->G, h->cfg.rank, h->cfg.world, h->device, upd, h->P, h->KTILE, h->rs_turns > 0 ? h->rs_turns : h->sets,
                  h->wg_stride > 1 ? 1 : 0, h->rowsplit ? h->R : 1, h->herm ? 1 : 0, (h->econ || h->econ_gen) ? 1 : 0, h->poll_delay, known, exn[h->exchange & 3], (double)h->spin_ticks / 1e5,
-                 h->pack_words_d ? "on" : "off", (h->rowsplit && h->R > 1) ? "on" : "n/a", (h->pulse_check && !h->rowsplit && !h->gen_update) ? "on" : "n/a",
+                 h->pack_words_d ? "on" : "off", (h->rowsplit && h->R > 1) ? "on" : "n/a", h->pulse_check ? "on" : "n/a",
                  (h->gen_update || opt_int(h, "MAIL_SELFTEST", 1) == 0) ? "off" : (h->quarantined ? "passed after setting blocks aside" : "passed"),
                  opt_int(h, "UC_POOL", 1) == 0 ? "; WARNING: UC_POOL=0 (diagnostics only): uncached mailboxes are freed again, and blocks that reuse their address range lose stores on this platform" : "",
                  h->plan_note.empty() ? "" : "; note: ", h->plan_note.c_str());
@@ -2093,7 +2109,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     a.init = h->psi0_d; a.store = h->store_fw ? h->Phi_d : nullptr; a.fin = h->psiT_d;
     a.X = h->X_d; a.alpha = h->S_d; a.eps_new = eps_new_dev; a.g_a_int = h->gint_d;
     a.dir = +1;
-    a.coh = (h->pulse_check && !calib_steps && !h->rowsplit) ? h->mail_d + KR_MAIL_COH_OFF : nullptr;   // (zeroed with the mailbox, below)
+    a.dulog = h->dulog_d;
     a.epoch_base = h->epoch_base;
     h->last_epoch_base = h->epoch_base;
     // next launch: first tag = last tag + 3 (odd step: buffer parity keeps alternating); 32-bit wrap-around is
@@ -2133,8 +2149,10 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     h->tl_launch1 = now_ms();
     rc = ev_mark(h, 2, true);
     if (rc) return rc;
-    if (a.coh) {   // every workgroup formed the same pulse in every step (outside the timed kernel, ~3 us)
-        hipLaunchKernelGGL(kr_pulse_check, dim3(1), dim3(256), 0, h->stream, a.coh, h->P, h->status_d);
+    if (a.dulog && !calib_steps) {   // eps_new from workgroup 0's totals; every workgroup gathered the same totals in every step (~5 us)
+        const size_t n = (size_t)h->cfg.L * h->cfg.NT;
+        hipLaunchKernelGGL(kr_pulse_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, eps_guess_dev, (const double *)h->S_d, (const double *)a.dulog,
+                           eps_new_dev, h->P, h->cfg.L, h->LMAXv, h->cfg.NT, h->pulse_check ? 1 : 0, h->status_d);
         HIPCHK(h, hipGetLastError());
     }
     return KR_OK;
@@ -2231,8 +2249,8 @@ static int check_status(kr_handle *h) {
             return fail(h, KR_ERR_INTERNAL, "the %s generator pack on the device no longer matches the operators kr_create uploaded (checksum mismatch in front of a sweep): device memory was corrupted; results of this call are invalid -- create a new handle",
                         st[2] == 0 ? "forward" : st[2] == 1 ? "adjoint (backward-sweep)" : st[2] == 2 ? "dense (matrix-core)" : st[2] == 3 ? "column-major forward" : "column-major adjoint");
         if (st[1] == 8)
-            return fail(h, KR_ERR_INTERNAL, "update sweep: workgroup %u formed other pulse values than workgroup 0 in at least one step (their coherence words differ: a partial sum of the per-step exchange was lost or accepted stale in one workgroup's gather); results of this call are invalid",
-                        st[2]);
+            return fail(h, KR_ERR_INTERNAL, "update sweep: workgroup %u gathered other totals than workgroup 0 and formed another pulse value (control %u, step %u: a partial sum of the per-step exchange was lost or accepted stale in one workgroup's gather); results of this call are invalid",
+                        st[2], st[3] / (unsigned)h->cfg.NT, st[3] % (unsigned)h->cfg.NT);
         if (st[1] == 9)
             return fail(h, KR_ERR_INTERNAL, "mailbox self-test failed (workgroup %u, round %u): device memory of this process loses stores or hides them from some XCDs", st[2] & 0xffffu, (st[2] >> 16) & 0xffu);
         if (st[1] == 6)

@@ -11,10 +11,19 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
+# The GPU tests put several shards (device list {0, 0}) or several ranks on the ONE GPU of the box.  Their persistent kernels wait for
+# each other, so every shard's stream needs a hardware queue of its own, and HIP multiplexes a process's streams over
+# GPU_MAX_HW_QUEUES (default 4) queues: a cached RCCL communicator (round 5: kept for the life of the process) or PyTorch's own
+# streams take some of them, and two shards that end up on one queue time out in their first exchange (seen: the RCCL test in front of
+# the device-list tests).  A test facility -- with one shard per GPU the question does not arise.  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "needs_hip_lib: needs libkrotov_hip.so (hipcc to build it), but no GPU")
+    config.addinivalue_line("markers", "soak: long fuzz / soak / micro-benchmark legs of the GPU suite; skipped unless KROTOV_RUN_SOAK=1 or '-m soak' "
+                                       "(the builder's own gpurun sessions; every BASELINE config and kernel family stays in the default selection)")
 
 
 def _have_hipcc():
@@ -24,6 +33,12 @@ def _have_hipcc():
 def pytest_collection_modifyitems(config, items):
     """CPU-only tests of the oracle and of the host logic must run on a machine without hipcc; only the tests that
     load libkrotov_hip.so (gpu / needs_hip_lib) require the HIP build."""
+    want_soak = os.environ.get("KROTOV_RUN_SOAK", "") not in ("", "0") or "soak" in (config.getoption("-m") or "")
+    if not want_soak:
+        skip_soak = pytest.mark.skip(reason="soak leg: set KROTOV_RUN_SOAK=1 or select with -m soak")
+        for it in items:
+            if "soak" in it.keywords:
+                it.add_marker(skip_soak)
     lib = os.path.join(ROOT, "krotov.jl_amd", "lib", "libkrotov_hip.so")
     if _have_hipcc() or os.path.exists(lib):
         return

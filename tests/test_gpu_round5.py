@@ -26,7 +26,7 @@ def test_pulse_coherence_words_find_a_planted_fault(shape, oracle_c):
     with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
         info = eng.info()
         assert info["generic_update"] == 0 and info["rowsplit_R"] == 0 and info["workgroups"] >= 2, eng.plan()
-        assert "pulse coherence words on" in eng.plan() and "mailbox self-test passed" in eng.plan(), eng.plan()
+        assert "per-step totals of all workgroups compared on" in eng.plan() and "mailbox self-test passed" in eng.plan(), eng.plan()
         eng.set_initial_states(p["psi0"])
         psiT = eng.forward(p["eps"])
         _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
@@ -38,9 +38,9 @@ def test_pulse_coherence_words_find_a_planted_fault(shape, oracle_c):
         eng.forward(p["eps"])
         with pytest.raises(kr.KrotovHipError) as ei:
             eng.iteration(p["eps"], chiT, p["S"], p["lam"])
-        assert ei.value.code == capi.KR_ERR_INTERNAL and "workgroup 1 formed other pulse values" in str(ei.value), str(ei.value)
+        assert ei.value.code == capi.KR_ERR_INTERNAL and "workgroup 1 gathered other totals than workgroup 0" in str(ei.value), str(ei.value)
     with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, options={"PULSE_CHECK": 0, "PULSE_FAULT": 1}) as eng:   # check off: nothing posted, nothing found
-        assert "pulse coherence words n/a" in eng.plan()
+        assert "per-step totals of all workgroups compared n/a" in eng.plan()
         eng.set_initial_states(p["psi0"])
         eng.forward(p["eps"])
         assert np.array_equal(eng.iteration(p["eps"], chiT, p["S"], p["lam"])[0], eps_new)
