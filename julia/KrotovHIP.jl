@@ -2,7 +2,7 @@
 #
 # UNTESTED: there is no Julia toolchain in the build image (the runnable stand-in for these `ccall`s is the C99 consumer
 # tests/abi_consumer.c, which drives the same entry points in the same order).  This file follows include/krotov_hip.h
-# (ABI v2) field for field; INTEGRATION.md explains every hook below against the reference's file:line.
+# (ABI v3) field for field; INTEGRATION.md explains every hook below against the reference's file:line.
 #
 #     using Krotov, QuantumControl, KrotovHIP
 #     problem = ControlProblem(trajectories, tlist; prop_method = KrotovHIP, J_T = J_T_sm, iter_stop = 5, ...)
@@ -92,10 +92,13 @@ mutable struct HIPPropagator
     parameters::Any
     backward::Bool
     kwargs::Dict{Symbol,Any}      # engine options given as prop_* kwargs: devices, hip_prop_method, prop_tol, spin_timeout_ms
+    t::Float64                    # time of `state` while per-step callbacks are replayed (what a callback reads besides `state`)
+    i::Int                        # ... and its index into tlist
 end
 
 function QP.init_prop(state, generator, tlist, ::Val{:KrotovHIP}; backward = false, parameters = nothing, kwargs...)
-    return HIPPropagator(generator, state, Vector{Float64}(tlist), parameters, backward, Dict{Symbol,Any}(kwargs))
+    tl = Vector{Float64}(tlist)
+    return HIPPropagator(generator, state, tl, parameters, backward, Dict{Symbol,Any}(kwargs), backward ? tl[end] : tl[1], backward ? length(tl) : 1)
 end
 QP.prop_step!(::HIPPropagator) = error("KrotovHIP: the engine owns whole sweeps; there is no per-step propagation (kr_read_storage inspects stored states)")
 QP.reinit_prop!(::HIPPropagator, state; kwargs...) = error("KrotovHIP: reinit_prop! is part of the sweeps the engine owns")
@@ -212,11 +215,38 @@ function pack_pulses(eps)
     return out
 end
 
+"""Per-step propagation callbacks (`wrk.fw_prop_kwargs[k][:callback]` / `wrk.bw_prop_kwargs[k][:callback]`, fired by the reference
+after every `prop_step!`: optimize.jl:258-262 initial sweep, :310-314 backward sweep, :362-366 update sweep).  The engine runs whole
+sweeps, so they are REPLAYED from the device storages right after the sweep, in the reference's order -- for k, for n -- with the
+propagator placeholder carrying the state, time and grid index of that step (`kr_read_storage`; forward storage slot n + 1 after
+step n, backward slot n: optimize.jl:263,315,367).  A callback therefore sees every state the reference would have shown it; what it
+cannot do is influence the sweep that has already run (the reference's own callbacks only observe).  Needs the forward storage
+(the default); the final states are put back afterwards."""
+function replay_prop_callbacks!(eng::Engine, wrk, which::Symbol)
+    props = which == :bw ? wrk.bw_propagators : wrk.fw_propagators
+    kws = which == :bw ? wrk.bw_prop_kwargs : wrk.fw_prop_kwargs
+    for k = 1:eng.K
+        haskey(kws[k], :callback) || continue
+        cb = kws[k][:callback]
+        observables = get(kws[k], :observables, nothing)      # (the reference's default is its private _StoreState(); a callback that asks for it gets `nothing`)
+        p = props[k]
+        steps = which == :bw ? (eng.NT:-1:1) : (2:eng.NT+1)  # storage slots in the order the sweep filled them
+        for slot in steps
+            put_state!(p, read_storage(eng, which, k, slot))
+            p.i = slot
+            p.t = p.tlist[slot]
+            cb(p, observables)
+        end
+    end
+end
+has_prop_callbacks(wrk, which::Symbol) = any(kw -> haskey(kw, :callback), which == :bw ? wrk.bw_prop_kwargs : wrk.fw_prop_kwargs)
+
 """All-k replacement of the body of `krotov_initial_fw_prop!` (optimize.jl:247-265)."""
 function initial_fw_prop!(eng::Engine, eps0, wrk)
     e = pack_pulses(eps0)
     psiT = Matrix{ComplexF64}(undef, eng.N, eng.K)
     GC.@preserve e psiT check(eng.handle, ccall((:kr_forward, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}), eng.handle, e, psiT))
+    has_prop_callbacks(wrk, :fw) && replay_prop_callbacks!(eng, wrk, :fw)   # optimize.jl:258-262
     for k = 1:eng.K
         put_state!(wrk.fw_propagators[k], view(psiT, :, k))          # what update_result! reads (optimize.jl:379)
     end
@@ -241,6 +271,8 @@ function iteration!(eng::Engine, wrk, eps_i, eps_ip1)
     for l = 1:eng.L
         eps_ip1[l] .= view(e_new, :, l)                               # in place: callbacks hold these vectors (test_iterations.jl:125-143)
     end
+    has_prop_callbacks(wrk, :bw) && replay_prop_callbacks!(eng, wrk, :bw)   # optimize.jl:310-314
+    has_prop_callbacks(wrk, :fw) && replay_prop_callbacks!(eng, wrk, :fw)   # optimize.jl:362-366
     for k = 1:eng.K
         put_state!(wrk.fw_propagators[k], view(psiT, :, k))
     end

@@ -57,8 +57,9 @@ struct KrSweepArgs {
     unsigned long long *peer_xmail[8]; // every rank's xmail (peer_xmail[rank] == xmail)
     double2 *U;              // [NT][NP*NP] precomputed step propagators, thread-major (kr_device_prop.h), or nullptr
     unsigned long long *gmail; // row-split kernels: per-trajectory vector mailbox [tiles][2][NP][4] granules
-    int rs_fault;              // diagnostics (option RS_FAULT=1): workgroup 1 flips one bit of its copy of the final state vector, so that the
-                               // coherence check of the group (kr_rowsplit_check) has something to find (tests)
+    int rs_fault;              // diagnostics (option RS_FAULT=w): workgroup w of a row-split launch flips one bit of its copy of the final state vector, so that
+                               // the coherence check of the group (kr_rowsplit_check) has something to find (tests; w = 1: tile 0, w = R + 1: tile 1, ...);
+                               // option PULSE_FAULT sets it to 2 for the N <= 64 kernels: workgroup 1 logs a wrong total at step 3 (kr_pulse_finish)
     int rs_sets;               // row-split PAIR mode: pairs a group of workgroups carries in turn (1: one pair per group)
     double2 *rs_scratch;       // ... and the per-workgroup scratch of their state vectors [P][KR_PAIR_MAX_SETS][2][NP] (rs_sets > 1)
     unsigned epoch_base2;    // tag base of the vector mailbox for this launch
@@ -85,6 +86,12 @@ struct KrSweepArgs {
     // logs bit for bit (status code 8): a workgroup that summed a stale or lost partial sum has propagated with another pulse than its
     // neighbours.  optimize.jl:351-358: ONE pulse value per step, whoever consumes it.
     double *dulog;
+    // Non-linear controls, static part (round 5 on the persistent update kernels; kr_config.control_poly): H(eps) = H0 + sum_l f_l(eps_l) H_l
+    // with polynomial f_l of degree <= 3, mu_l = f_l'(eps_guess) H_l (_eval_mu, optimize.jl:268-272,337,345).  The host hands the update
+    // sweep what depends on the GUESS only -- amp_g[l][n] = f_l(eps_guess), fprime_g[l][n] = f_l'(eps_guess), both [L][NT] -- and the
+    // coefficients poly[l][0..3] for the one evaluation per step that cannot be made in advance, f_l(eps_new).  (Known-pulse sweeps need
+    // nothing: they are launched with the amplitudes f_l(eps) in the place of the pulses.)  All three nullptr: linear controls.
+    const double *amp_g, *fprime_g, *poly;
     // Known-pulse sweeps in blocks of time (round 5; kr_device_tblock.h, NP = 64): steps [b S, (b + 1) S) form block b; tb_bound holds
     // the state at every block boundary ([NB + 1][Kp][N], written by the sequential apply sweep over the block propagators),
     // tb_items the trajectory ranges one workgroup carries ({first slot, count <= 64, generator, 0} per item).

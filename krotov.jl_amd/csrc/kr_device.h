@@ -863,7 +863,15 @@ __device__ __forceinline__ bool kr_exchange(const KrSweepArgs &a, const int n, c
 // leaves the critical path of the step.  chi(t_{n+1}) must then be in LDS one step earlier (prefetch distance 2).
 // XLOC = 1: the launch uses the one-XCD placement (KrSweepArgs::wg_stride > 1, P <= 32 workgroups).  A template parameter, not a
 // run-time flag: as a flag it cost the big grids 2 % (C3: 5.55 -> 5.65 us per step, same-box A/B) for a path they never take.
-template <int NP, int LMAX, int KT, int SCHED, int CAL, int HERM, int XLOC = 0>
+// POLY = 1 (round 5): non-linear controls with polynomial amplitudes f_l of degree <= 3 (KrSweepArgs::poly): the matrices are combined
+// with f_l(eps_l) instead of eps_l, the totals are scaled by f_l'(eps_guess) before the pulse update.  A separate instantiation: the
+// linear kernel's code is untouched.
+// The amplitude's change f_l(eg + d) - f_l(eg) for a cubic f_l, exactly, as its Taylor polynomial at the guess value: d (f' + d (f''/2 + d c3)).
+// f' = f_l'(eg) comes with the step's prefetched scalars, f''/2 = c2 + 3 c3 eg is one FMA that needs no total, c2 and c3 are loaded once:
+// nothing but three dependent FMAs joins the critical path behind the exchange (evaluating f_l(eps_new) from its coefficients there --
+// scalar loads and a wait that also covers every LDS operation in flight -- cost C3 0.6 us per step).
+__device__ __forceinline__ double kr_poly3_delta(const double d, const double fp, const double f2, const double c3) { return d * fma(d, fma(d, c3, f2), fp); }
+template <int NP, int LMAX, int KT, int SCHED, int CAL, int HERM, int XLOC = 0, int POLY = 0>
 __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, KT>::THREADS / 256)) void kr_sweep_update(const KrSweepArgs a) {
     using G = KrGeom<NP, LMAX, KT>;
     constexpr int JS = G::JS, JQ = G::JQ, RT = G::RT, SG = G::SG, KTILE = G::KTILE, NPP = G::NPP, NW = G::NW;
@@ -997,6 +1005,17 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
     int cur = 0;
     // guess pulse, step size alpha = S/lambda and dt of the NEXT step are fetched one step ahead
     double eg_nx[LMAX], al_nx[LMAX], dt_nx = a.dt[0];
+    // POLY: the coefficients of f_l (uniform: scalar registers); f_l(eps_guess) and f_l'(eps_guess) are formed at the top of the step,
+    // in the shadow of the exchange (arrays of them, prefetched like eps_guess, cost eight more VGPRs: the HERM variant then spilled)
+    double pc0[POLY ? LMAX : 1], pc1[POLY ? LMAX : 1], pc2[POLY ? LMAX : 1], pc3[POLY ? LMAX : 1];
+    if (POLY) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            // (v_readfirstlane: the compiler kept them in vector registers otherwise -- 16 VGPRs the HERM variant does not have)
+            pc0[l] = kr_readlane_f64((l < L) ? a.poly[4 * l] : 0.0, 0); pc1[l] = kr_readlane_f64((l < L) ? a.poly[4 * l + 1] : 0.0, 0);
+            pc2[l] = kr_readlane_f64((l < L) ? a.poly[4 * l + 2] : 0.0, 0); pc3[l] = kr_readlane_f64((l < L) ? a.poly[4 * l + 3] : 0.0, 0);
+        }
+    }
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
         eg_nx[l] = (l < L) ? a.eps[(size_t)l * NT] : 0.0;
@@ -1018,6 +1037,7 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         double eg[LMAX], al[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) { eg[l] = eg_nx[l]; al[l] = al_nx[l]; }
+
         if (n + 1 < NT) {
             dt_nx = a.dt[n + 1];
             if (econ_rows) ec_nx = econ_rows[(size_t)(n + 1) * KR_ECON_W];
@@ -1033,6 +1053,9 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
         for (int l = 0; l < LMAX; ++l) part[l] = 0.0;
         // H(eps_guess) of this step (eps_guess is known in advance; exact, no drift), b = H(eps_guess) psi, a_l = H_l psi
         auto form_E = [&]() {
+            double agl[LMAX];   // the amplitudes the matrices are combined with: f_l(eps_guess) (POLY), or eps_guess itself
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) agl[l] = POLY ? fma(fma(fma(pc3[l], eg[l], pc2[l]), eg[l], pc1[l]), eg[l], pc0[l]) : eg[l];
 #pragma unroll
             for (int jj = 0; jj < JS; ++jj) {
                 double r, im;
@@ -1040,8 +1063,8 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
                 else { r = Hr[0][jj]; im = Hi[0][jj]; }
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) {
-                    r = fma(eg[l], Hr[1 + l][jj], r);
-                    im = fma(eg[l], Hi[1 + l][jj], im);
+                    r = fma(agl[l], Hr[1 + l][jj], r);
+                    im = fma(agl[l], Hi[1 + l][jj], im);
                 }
                 Er[jj] = r;
                 Ei[jj] = im;
@@ -1164,12 +1187,17 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, KT>::THREADS), (KrGeom<NP, LMAX, 
             e[l] = 0.0; de[l] = 0.0;
             if (l < L) {
                 const double alpha = al[l];  // = S[l][n] / lambda[l], IEEE division done once on the host
-                const double deps = __dmul_rn(alpha, du[l]);
+                // POLY: mu_l = f_l'(eps_guess) H_l -- the total of Im<chi|H_l|psi> times the derivative at the guess value (optimize.jl:337,345)
+                const double fpl = POLY ? fma(fma(3.0 * pc3[l], eg[l], 2.0 * pc2[l]), eg[l], pc1[l]) : 1.0;   // f_l'(eps_guess)
+                const double dul = POLY ? __dmul_rn(fpl, du[l]) : du[l];
+                const double deps = __dmul_rn(alpha, dul);
                 e[l] = __dadd_rn(eg[l], deps);
-                de[l] = e[l] - eg[l];  // what H(eps_guess) has to be corrected by (== deps up to rounding)
-                const double ad = fabs(du[l]);
+                // what H(eps_guess) has to be corrected by: the change of the AMPLITUDE (== deps up to rounding for linear controls)
+                de[l] = POLY ? kr_poly3_delta(e[l] - eg[l], fpl, fma(3.0 * pc3[l], eg[l], pc2[l]), pc3[l]) : (e[l] - eg[l]);
+                const double an = POLY ? fma(fma(fma(pc3[l], e[l], pc2[l]), e[l], pc1[l]), e[l], pc0[l]) : e[l];   // (only the step's norm bound needs it)
+                const double ad = fabs(dul);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dt));
-                theta += fabs(e[l]) * gx.nrm[1 + l];
+                theta += fabs(an) * gx.nrm[1 + l];
             }
         }
         theta *= fabs(dt);
@@ -1320,6 +1348,14 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
         else if ((kind & 15) == 1 && (kind & 128)) {  /* one-XCD placement (P <= 32, no calibration): window variant (wave 1 publishes) or general variant (classic schedule) */ \
             if (kind & 64) kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 1, 0, 1, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
             else kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 0, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
+        } \
+        else if ((kind & 15) == 1 && (kind & 256)) {  /* non-linear controls (POLY): both schedules, both variants, no calibration build, no one-XCD placement */ \
+            switch ((kind >> 4) & 5) { \
+            case 0: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 0, 0, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            case 1: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 1, 0, 0, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            case 4: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 0, 0, 1, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            default: kr_launch_kernel((kr_sweep_update<NP, LM, KTv, 1, 0, 1, 0, 1>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); break; \
+            } \
         } \
         else if ((kind & 15) == 1) {  /* update sweep: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 */ \
             switch (kind >> 4) { \

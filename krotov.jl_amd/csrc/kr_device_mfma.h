@@ -136,7 +136,8 @@ __device__ __forceinline__ void kr_mf_put(double2 *W, const int doff, const int 
 // and the Horner ping-pong are shared; per set ONE psi array and ONE chi array (no parity pair: psi(t_{n+1}) overwrites psi(t_n)
 // in place once the exchange's barriers lie behind every reader, chi(t_{n+1}) is handed over after the set's rounds), 16 KB per
 // set at two tiles -> 4 sets in 144 KB.  The general (non-HERM) variant only.
-template <int LMAX, int TILES, int SCHED, int HERM, int CAL, int SETS = 1>
+// POLY = 1 (round 5): polynomial amplitudes f_l of degree <= 3 (kr_sweep_update, kr_device.h): a separate instantiation.
+template <int LMAX, int TILES, int SCHED, int HERM, int CAL, int SETS = 1, int POLY = 0>
 __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     static_assert(SETS == 1 || HERM == 0, "several sets per workgroup: general variant only");
     constexpr int KT = 2 * TILES, TW = KR_MF_TW, NW = 4;
@@ -249,10 +250,17 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
     if (stamp) { t_prev = __builtin_amdgcn_s_memtime(); rt0 = kr_realtime(); }
     int cur = 0;
     double eg_nx[LMAX], al_nx[LMAX], dt_nx = a.dt[0];
+    double fp_nx[POLY ? LMAX : 1], ag_nx[POLY ? LMAX : 1];   // POLY: f_l'(eps_guess), f_l(eps_guess) of the next step
+    double pc2[POLY ? LMAX : 1], pc3[POLY ? LMAX : 1];       //       the quadratic and cubic coefficients of f_l
+    if (POLY) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { pc2[l] = (l < L) ? a.poly[4 * l + 2] : 0.0; pc3[l] = (l < L) ? a.poly[4 * l + 3] : 0.0; }
+    }
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
         eg_nx[l] = (l < L) ? a.eps[(size_t)l * NT] : 0.0;
         al_nx[l] = (l < L) ? a.alpha[(size_t)l * NT] : 0.0;
+        if (POLY) { fp_nx[l] = (l < L) ? a.fprime_g[(size_t)l * NT] : 0.0; ag_nx[l] = (l < L) ? a.amp_g[(size_t)l * NT] : 0.0; }
     }
     const double *econ_rows = a.econ ? a.econ + ((size_t)gx.gen * NT) * KR_ECON_W + (lane & (KR_ECON_W - 1)) : nullptr;
     double ec_nx = econ_rows ? econ_rows[0] : 0.0;
@@ -263,12 +271,19 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
         double eg[LMAX], al[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) { eg[l] = eg_nx[l]; al[l] = al_nx[l]; }
+        double fpg[POLY ? LMAX : 1], ag[POLY ? LMAX : 1];
+        if (POLY) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) { fpg[l] = fp_nx[l]; ag[l] = ag_nx[l]; }
+        }
         if (n + 1 < NT) {
             dt_nx = a.dt[n + 1];
             if (econ_rows) ec_nx = econ_rows[(size_t)(n + 1) * KR_ECON_W];
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l)
+            for (int l = 0; l < LMAX; ++l) {
                 if (l < L) { eg_nx[l] = a.eps[(size_t)l * NT + n + 1]; al_nx[l] = a.alpha[(size_t)l * NT + n + 1]; }
+                if (POLY && l < L) { fp_nx[l] = a.fprime_g[(size_t)l * NT + n + 1]; ag_nx[l] = a.amp_g[(size_t)l * NT + n + 1]; }
+            }
         }
         // D[set][m][t] = packed(-i H_m psi)[this lane], m = 0 (drift), 1..L (controls)
         double D[SETS][LMAX + 1][TILES];
@@ -383,8 +398,12 @@ __global__ __launch_bounds__(256, 1) void kr_mf_update(const KrSweepArgs a) {
             e[l] = 0.0;
             if (l < L) {
                 const double alpha = al[l];
-                e[l] = __dadd_rn(eg[l], __dmul_rn(alpha, du[l]));
-                const double ad = fabs(du[l]);
+                // POLY: mu_l = f_l'(eps_guess) H_l (optimize.jl:337,345); e[l] then holds the AMPLITUDE f_l(eps_new) the matrices are combined
+                // with (the pulse value itself is formed behind the sweep, kr_pulse_finish)
+                const double dul = POLY ? __dmul_rn(fpg[l], du[l]) : du[l];
+                const double en = __dadd_rn(eg[l], __dmul_rn(alpha, dul));
+                e[l] = POLY ? (ag[l] + kr_poly3_delta(en - eg[l], fpg[l], fma(3.0 * pc3[l], eg[l], pc2[l]), pc3[l])) : en;
+                const double ad = fabs(dul);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dtn));
                 theta += fabs(e[l]) * gx.nrm[1 + l];
             }
@@ -656,6 +675,17 @@ static hipError_t kr_launch_mfma64(int tiles, int kind, int grid, hipStream_t s,
         }                                                                                                          \
         return hipGetLastError();                                                                                  \
     }
+    // non-linear controls (kind bit 256): both schedules, both variants, one set
+#define KR_CASE_P(TL)                                                                                              \
+    if ((kind & 256) && tiles == TL) {                                                                             \
+        switch (v & 3) {                                                                                           \
+        case 0: kr_launch_kernel((kr_mf_update<LM, TL, 0, 0, 0, 1, 1>), grid, 256, 0, s, *a); break;     \
+        case 1: kr_launch_kernel((kr_mf_update<LM, TL, 1, 0, 0, 1, 1>), grid, 256, 0, s, *a); break;     \
+        case 2: kr_launch_kernel((kr_mf_update<LM, TL, 0, 1, 0, 1, 1>), grid, 256, 0, s, *a); break;     \
+        default: kr_launch_kernel((kr_mf_update<LM, TL, 1, 1, 0, 1, 1>), grid, 256, 0, s, *a); break;    \
+        }                                                                                                          \
+        return hipGetLastError();                                                                                  \
+    }
     // several sets per workgroup (tiles argument = tiles | sets << 8): two tiles, general variant only
 #define KR_CASE_S(ST)                                                                                              \
     if (tiles == (2 | (ST << 8))) {                                                                                \
@@ -670,10 +700,12 @@ static hipError_t kr_launch_mfma64(int tiles, int kind, int grid, hipStream_t s,
 #ifdef KR_MF_ONLY_TILES
     KR_CASE_M(KR_MF_ONLY_TILES)
 #else
+    KR_CASE_P(1) KR_CASE_P(2)
     KR_CASE_M(1) KR_CASE_M(2)   // (4 tiles: the vector arrays + H0 exceed the CU's LDS and the accumulators spill)
     KR_CASE_S(2) KR_CASE_S(4)
 #endif
 #undef KR_CASE_M
+#undef KR_CASE_P
 #undef KR_CASE_S
     return hipErrorInvalidValue;
 }

@@ -517,7 +517,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
         // its LDS copy behind the mailboxes (the XCC-id table's slots: their job ended at kernel start); kr_rowsplit_check
         // (krotov_hip.hip) compares them after the launch and turns a difference into a status instead of a silently wrong sweep.
         __shared__ unsigned long long scs[G::THREADS / 64];
-        if (a.rs_fault && wg == 1 && tid == 0) { sx[cur][0].x = __longlong_as_double(__double_as_longlong(sx[cur][0].x) ^ 2ll); }   // (tests: a fault to find)
+        if (a.rs_fault && wg == a.rs_fault && tid == 0) { sx[cur][0].x = __longlong_as_double(__double_as_longlong(sx[cur][0].x) ^ 2ll); }   // (tests: a fault to find)
         if (a.rs_fault) __syncthreads();
         unsigned long long cs = 0ull;
         for (int e = tid; e < NP; e += G::THREADS) {
@@ -773,7 +773,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     }
     {
         __shared__ unsigned long long scs[T / 64];
-        if (a.rs_fault && wg == 1 && tid == 0) coh ^= 2ull;   // (tests: a fault to find)
+        if (a.rs_fault && wg == a.rs_fault && tid == 0) coh ^= 2ull;   // (tests: a fault to find)
         for (int o = 1; o < 64; o <<= 1) coh ^= __shfl_xor(coh, o, 64);
         if (lane == 0) scs[tid >> 6] = coh;
         __syncthreads();

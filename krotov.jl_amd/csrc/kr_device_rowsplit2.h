@@ -692,7 +692,7 @@ kr_next_set:
         for (int q = 0; q < KP; ++q) a.fin[kbase[q] + row] = make_double2(pr[q], pim[q]);
     }
     if constexpr (!(MULTI && UPDATE)) {
-        if (a.rs_fault && wg == 1 && tid == 0 && kset == 0) sx[1][cur][0].x = __longlong_as_double(__double_as_longlong(sx[1][cur][0].x) ^ 2ll);   // (tests: a fault to find)
+        if (a.rs_fault && wg == a.rs_fault && tid == 0 && kset == 0) sx[1][cur][0].x = __longlong_as_double(__double_as_longlong(sx[1][cur][0].x) ^ 2ll);   // (tests: a fault to find)
         if (a.rs_fault) __syncthreads();
         KR_PAIR_FOLD(kset, cur)
     }
@@ -702,7 +702,7 @@ kr_next_set:
 #undef KR_PAIR_FOLD
     {
         __shared__ unsigned long long scs[T / 64];
-        if (MULTI && UPDATE && a.rs_fault && wg == 1 && tid == 0) coh ^= 2ull;   // (tests: a fault to find)
+        if (MULTI && UPDATE && a.rs_fault && wg == a.rs_fault && tid == 0) coh ^= 2ull;   // (tests: a fault to find)
         for (int o = 1; o < 64; o <<= 1) coh ^= __shfl_xor(coh, o, 64);
         __syncthreads();
         if (lane == 0) scs[wave] = coh;

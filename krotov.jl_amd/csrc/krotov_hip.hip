@@ -146,6 +146,11 @@ struct kr_handle {
     int method = KR_PROP_AUTO;         // kr_prop_method; Chebyshev / Newton run on the generic kernels
     double *ptab_d = nullptr, *erange_d = nullptr;
     double *poly_d = nullptr;          // non-linear controls: [L][poly_deg + 1] coefficients of f_l (generic kernels), or nullptr
+    // ... on the persistent kernels (round 5): the known-pulse sweeps of every family are launched with the amplitudes f_l(eps) in the
+    // place of the pulses (amp_d); the N <= 64 update kernels have instantiations for degree <= 3 (poly_fast: coefficients padded to
+    // four per control in poly3_d, f_l(eps_guess) in amp_d and f_l'(eps_guess) in fprime_d, rewritten in front of every sweep)
+    bool poly_fast = false;
+    double *poly3_d = nullptr, *amp_d = nullptr, *fprime_d = nullptr;
     int poly_deg = 0;
     int ptab_stride = 0;
     double lam0 = 0.0;                 // max over generators of the norm bound of H0
@@ -465,13 +470,30 @@ __global__ void kr_rowsplit_check(const unsigned long long *words, int tiles, in
 // eps + (S / lambda) du, one rounded product, one rounded sum) and compares all P logs bit for bit: a workgroup that summed a
 // stale or lost partial sum once has propagated with another pulse than its neighbours (status code 8, with workgroup, control and
 // step).  optimize.jl:351-358 has ONE pulse value per step.
-__global__ __launch_bounds__(256) void kr_pulse_finish(const double *eps_guess, const double *alpha, const double *dulog, double *eps_new, int P, int L, int LMAX, int NT,
-                                                       int check, unsigned *status) {
+// Non-linear controls on the persistent kernels: amp[l][n] = f_l(eps[l][n]) and (optionally) fprime[l][n] = f_l'(eps[l][n]) for
+// polynomial f_l (coefficients poly[l][0..deg], as kr_gen_f / kr_gen_fprime of the generic kernels evaluate them).
+__global__ __launch_bounds__(256) void kr_poly_eval(const double *eps, const double *poly, int deg, int L, int NT, double *amp, double *fprime) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)L * NT) return;
+    const double *cf = poly + (size_t)(i / NT) * (deg + 1);
+    const double x = eps[i];
+    double v = cf[deg];
+    for (int p = deg - 1; p >= 0; --p) v = fma(v, x, cf[p]);
+    amp[i] = v;
+    if (fprime) {
+        double d = deg * cf[deg];
+        for (int p = deg - 1; p >= 1; --p) d = fma(d, x, p * cf[p]);
+        fprime[i] = d;
+    }
+}
+
+__global__ __launch_bounds__(256) void kr_pulse_finish(const double *eps_guess, const double *alpha, const double *fprime, const double *dulog, double *eps_new, int P, int L,
+                                                       int LMAX, int NT, int check, unsigned *status) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)L * NT) return;
     const int l = (int)(i / NT), n = (int)(i % NT);
     const double du = dulog[(size_t)n * LMAX + l];
-    eps_new[i] = __dadd_rn(eps_guess[i], __dmul_rn(alpha[i], du));
+    eps_new[i] = __dadd_rn(eps_guess[i], __dmul_rn(alpha[i], fprime ? __dmul_rn(fprime[i], du) : du));   // (fprime: mu_l = f_l'(eps_guess) H_l, non-linear controls)
     if (!check) return;
     const long long ref = __double_as_longlong(du);
     int who = 0;
@@ -879,10 +901,14 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
     const bool nonlinear = c.control_poly_degree > 0 && h->poly_deg > 0;
     if (nonlinear && (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON))
         return fail(h, KR_ERR_UNSUPPORTED, "non-linear controls with prop_method = CHEBY / NEWTON are not supported (use TAYLOR)");
-    const bool poly = (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON) || nonlinear;   // these live in the generic kernels
+    const bool poly = (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON);   // these live in the generic kernels
+    // (non-linear controls, round 5: the known-pulse sweeps of every persistent family take the amplitudes f_l(eps) in the place of the
+    //  pulses; the update sweep has persistent instantiations for N <= 64 and degree <= 3 -- beyond that the stepped generic update)
     int rc = (genv == 1 || poly) ? KR_ERR_UNSUPPORTED : make_plan_fast(h, tg, wg_gen, c.max_workgroups);
     h->fast_ok = (rc == KR_OK);
     if (rc != KR_OK && rc != KR_ERR_UNSUPPORTED) return rc;
+    if (nonlinear && h->fast_ok) h->wg_stride = 1;   // (no one-XCD placement build of the non-linear update kernels)
+    h->poly_fast = nonlinear && h->fast_ok && h->NP <= 64 && !h->rowsplit && h->poly_deg <= 3 && h->sets == 1 && c.exchange != KR_EXCHANGE_RCCL && c.exchange != KR_EXCHANGE_CALLBACK;
     if (h->fast_ok) {
         // Co-residency: the P persistent workgroups of an update sweep spin on each other, so all of them must be resident
         // at once.  Ask the runtime how many workgroups of the update kernel one CU holds (registers, LDS) and fail fast --
@@ -899,7 +925,7 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
         bool unknown = false;
         for (int sched = 0; sched < 2; ++sched) {
             int kind = 1;
-            if (h->NP <= 64 && !h->rowsplit) kind |= (sched ? 16 : 0) | (h->herm ? 64 : 0);
+            if (h->NP <= 64 && !h->rowsplit) kind |= (sched ? 16 : 0) | (h->herm ? 64 : 0) | (h->poly_fast ? 256 : 0);
             else if (sched) break;
             q.on = 1; q.blocks_per_cu = -2;
             if (h->rowsplit && h->rs_turns > 0) { dummy.rs_sets = h->rs_turns; dummy.rs_scratch = (double2 *)16; (void)h->launch_rs(h->LMAXv, h->NR, 5, h->P, nullptr, &dummy); }
@@ -920,10 +946,12 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
             rc = KR_ERR_UNSUPPORTED;
         }
     }
+    if (!h->fast_ok) h->poly_fast = false;
     if (!h->fast_ok && genv == 0 && !poly) return rc;
     // exchange
     int ex = c.exchange;
-    const bool update_fast = h->fast_ok && (h->rs_batch == 0 || h->rs_turns > 0);   // (batched row-split plan: only the known-pulse sweeps are persistent)
+    const bool update_fast = h->fast_ok && (h->rs_batch == 0 || h->rs_turns > 0) &&   // (batched row-split plan: only the known-pulse sweeps are persistent)
+                             (!nonlinear || h->poly_fast);                              // (non-linear controls beyond the persistent instantiations: stepped generic update)
     if (ex == KR_EXCHANGE_AUTO) ex = update_fast ? KR_EXCHANGE_MAILBOX : (c.world > 1 ? KR_EXCHANGE_RCCL : KR_EXCHANGE_MAILBOX);
     if (ex == KR_EXCHANGE_MAILBOX && !update_fast && c.world > 1)
         return fail(h, KR_ERR_UNSUPPORTED, "this problem runs on the generic kernels (%s); with world > 1 they need exchange = RCCL or CALLBACK", h->err.c_str());
@@ -980,7 +1008,7 @@ static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->pack_words_d, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d, h->skw_d,
                     h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d,
-                    h->tb_P_d, h->tb_bound_d, h->tb_items_d, h->dulog_d};
+                    h->tb_P_d, h->tb_bound_d, h->tb_items_d, h->dulog_d, h->poly3_d, h->amp_d, h->fprime_d};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected && !h->peers_in_process)   // (cached mappings stay open: ipc_open)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -1404,6 +1432,17 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     CHK(dalloc(&h->eps_a, (size_t)L * NT));
     CHK(dalloc(&h->eps_b, (size_t)L * NT));
     CHK(dalloc(&h->S_d, (size_t)L * NT));
+    if (h->poly_deg > 0 && h->fast_ok) {   // non-linear controls on the persistent kernels: amplitudes (and derivatives at the guess) of the sweep at hand
+        CHK(dalloc(&h->amp_d, (size_t)L * NT));
+        CHK(dalloc(&h->fprime_d, (size_t)L * NT));
+        if (h->poly_fast) {
+            std::vector<double> p3((size_t)L * 4, 0.0);
+            for (int l = 0; l < L; ++l)
+                for (int q = 0; q <= h->poly_deg; ++q) p3[(size_t)l * 4 + q] = cfg->control_poly[(size_t)l * (h->poly_deg + 1) + q];
+            CHK(dalloc(&h->poly3_d, p3.size()));
+            CHK(hipMemcpy(h->poly3_d, p3.data(), p3.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     CHK(dalloc(&h->lambda_d, L));
     CHK(dalloc(&h->gint_d, std::max(L, KR_LMAX_CAP)));
     const size_t slab = (size_t)h->Kp * N;
@@ -1964,6 +2003,13 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
     base_args(h, a);
     { const int prc = pack_precheck(h, h->gen_known ? (backward ? 4 : 3) : (backward ? 1 : 0)); if (prc) return prc; }
     a.Hpack = backward ? h->Hpack_bw : h->Hpack_fw;
+    if (h->poly_deg > 0 && !h->gen_known) {   // non-linear controls: the persistent kernels combine the matrices with f_l(eps_l)
+        const size_t n = (size_t)h->cfg.L * h->cfg.NT;
+        hipLaunchKernelGGL(kr_poly_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, eps_dev, (const double *)h->poly_d, h->poly_deg, h->cfg.L, h->cfg.NT,
+                           h->amp_d, (double *)nullptr);
+        HIPCHK(h, hipGetLastError());
+        eps_dev = h->amp_d;
+    }
     a.eps = eps_dev;
     a.init = init; a.store = store; a.fin = fin;
     a.dir = backward ? -1 : +1;
@@ -2110,6 +2156,15 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     a.X = h->X_d; a.alpha = h->S_d; a.eps_new = eps_new_dev; a.g_a_int = h->gint_d;
     a.dir = +1;
     a.dulog = h->dulog_d;
+    const double *econ_src = eps_guess_dev;   // what the economized rows are made from: the amplitudes the matrices are combined with
+    if (h->poly_fast && !calib_steps) {       // f_l(eps_guess), f_l'(eps_guess) of this sweep; the kernel evaluates f_l(eps_new) itself
+        const size_t n = (size_t)h->cfg.L * h->cfg.NT;
+        hipLaunchKernelGGL(kr_poly_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, eps_guess_dev, (const double *)h->poly_d, h->poly_deg, h->cfg.L,
+                           h->cfg.NT, h->amp_d, h->fprime_d);
+        HIPCHK(h, hipGetLastError());
+        a.amp_g = h->amp_d; a.fprime_g = h->fprime_d; a.poly = h->poly3_d;
+        econ_src = h->amp_d;
+    }
     a.epoch_base = h->epoch_base;
     h->last_epoch_base = h->epoch_base;
     // next launch: first tag = last tag + 3 (odd step: buffer parity keeps alternating); 32-bit wrap-around is
@@ -2117,7 +2172,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     h->epoch_base += (unsigned)h->cfg.NT + 2u;
     if (h->econ) {   // rows of the economized step polynomial from this sweep's guess pulses (device-resident pulses included)
         const int rows = h->G * h->cfg.NT;
-        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, eps_guess_dev, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT, std::min(h->cfg.L, KR_LMAX_CAP), 1 + KR_LMAX_CAP,
+        hipLaunchKernelGGL(kr_econ_rows_kernel, dim3(rows), dim3(64), 0, h->stream, econ_src, h->dt_d, h->nrm_d, h->skw_d, h->G, h->cfg.NT, std::min(h->cfg.L, KR_LMAX_CAP), 1 + KR_LMAX_CAP,
                            h->tol, 1.01, h->econ_d);
         HIPCHK(h, hipGetLastError());
         a.econ = h->econ_d;
@@ -2138,7 +2193,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     } else
     {   // update kernel variant: kind = 1 | SCHED << 4 | CAL << 5 | HERM << 6 (kr_launch_np); N <= 64 only
         int kind = 1;
-        if (h->NP <= 64) kind |= ((h->poll_delay >= 0) ? 16 : 0) | (calib_steps ? 32 : 0) | (h->herm ? 64 : 0);
+        if (h->NP <= 64) kind |= ((h->poll_delay >= 0) ? 16 : 0) | (calib_steps ? 32 : 0) | (h->herm ? 64 : 0) | ((h->poly_fast && !calib_steps) ? 256 : 0);
         if (h->mfma_sweep) HIPCHK(h, kr_launch_mf64(h->LMAXv, (h->KT / 2) | (h->sets > 1 ? h->sets << 8 : 0), kind, h->P, h->stream, &a));
         else {
             a.wg_stride = (h->NP <= 64 && !calib_steps) ? h->wg_stride : 1;
@@ -2151,7 +2206,7 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     if (rc) return rc;
     if (a.dulog && !calib_steps) {   // eps_new from workgroup 0's totals; every workgroup gathered the same totals in every step (~5 us)
         const size_t n = (size_t)h->cfg.L * h->cfg.NT;
-        hipLaunchKernelGGL(kr_pulse_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, eps_guess_dev, (const double *)h->S_d, (const double *)a.dulog,
+        hipLaunchKernelGGL(kr_pulse_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, eps_guess_dev, (const double *)h->S_d, a.fprime_g, (const double *)a.dulog,
                            eps_new_dev, h->P, h->cfg.L, h->LMAXv, h->cfg.NT, h->pulse_check ? 1 : 0, h->status_d);
         HIPCHK(h, hipGetLastError());
     }

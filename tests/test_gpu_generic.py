@@ -245,38 +245,52 @@ def test_polynomial_propagator_reports_a_control_that_leaves_its_range(oracle_c)
         assert ei.value.code == capi.KR_ERR_UNSUPPORTED and "left the range" in str(ei.value)
 
 
-def test_nonlinear_polynomial_controls():
+@pytest.mark.parametrize("shape,deg,persistent", [((10, 25, 6, 2), 3, 1), ((64, 12, 256, 2), 3, 1), ((64, 8, 600, 2), 2, 1), ((33, 9, 40, 3), 3, 1),
+                                                   ((10, 25, 6, 2), 5, 0), ((100, 6, 5, 1), 3, 0)],
+                         ids=["np16", "c3_shape_vector", "matrix_cores", "lmax4", "degree5_generic_update", "rowsplit_known_generic_update"])
+def test_nonlinear_polynomial_controls(shape, deg, persistent):
     """Non-linear controls, static part: H(eps) = H0 + sum_l f_l(eps_l) H_l with polynomial f_l; the
     control derivative mu_l = f_l'(eps_l) H_l is evaluated at the GUESS value of the step, as _eval_mu does
     (/root/reference/src/optimize.jl:268-272,337,345).  Against a serial restatement of optimize.jl:328-370 built on the
-    oracle's exact step propagator."""
+    oracle's exact step propagator.  Round 5: degree <= 3 at N <= 64 runs on the PERSISTENT update kernels (kr_sweep_update /
+    kr_mf_update<.., POLY>; generic_update == 0), the known-pulse sweeps of every persistent family take the amplitudes in the
+    place of the pulses; higher degrees and N > 64 keep the stepped generic update."""
     import krotov_oracle as o
-    p = wl.dense_problem(10, 25, 6, 2, 620, 0.1, 0.5)
+    N, NT, K, L = shape
+    p = wl.dense_problem(N, NT, K, L, 620 + N, 0.1 if N <= 16 else 0.05, 0.5)
     H0, Hc, tl, eps, S, lam, psi0, tgt = (p[k] for k in ("H0", "Hc", "tlist", "eps", "S", "lam", "psi0", "tgt"))
-    K, NT, L = 6, 25, 2
-    poly = np.array([[0.0, 1.0, 0.5, 0.0], [0.1, 0.8, 0.0, 2.0]])   # f_0 = x + x^2/2, f_1 = 0.1 + 0.8 x + 2 x^3
-    f = lambda l, x: sum(poly[l, q] * x ** q for q in range(4))
-    fp = lambda l, x: sum(q * poly[l, q] * x ** (q - 1) for q in range(1, 4))
+    rng = np.random.default_rng(621)
+    poly = np.zeros((L, deg + 1))
+    poly[0, :3] = [0.0, 1.0, 0.5]                       # f_0 = x + x^2 / 2
+    for l in range(1, L):
+        poly[l, :2] = [0.1, 0.8]
+        poly[l, deg] = 2.0 / l                          # f_l = 0.1 + 0.8 x + (2 / l) x^deg
+    f = lambda l, x: sum(poly[l, q] * x ** q for q in range(deg + 1))
+    fp = lambda l, x: sum(q * poly[l, q] * x ** (q - 1) for q in range(1, deg + 1))
     amp = lambda e: np.array([f(l, e[l]) for l in range(L)])
     with kr.HipEngine(H0, Hc, tl, K, control_poly=poly) as eng:
-        assert eng.info()["generic_update"] == 1
+        info = eng.info()
+        assert info["generic_update"] == (0 if persistent else 1), eng.plan()
+        assert info["generic_known"] == 0, eng.plan()
         eng.set_initial_states(psi0)
         psiT = eng.forward(eps)
+        Us = [o.step_propagator(H0, Hc, amp(eps[:, n]), tl[n + 1] - tl[n]) for n in range(NT)]
         psi = psi0.copy()
         for n in range(NT):
-            psi = psi @ o.step_propagator(H0, Hc, amp(eps[:, n]), tl[n + 1] - tl[n]).T
+            psi = psi @ Us[n].T
         assert np.max(np.abs(psiT - psi)) < 1e-11
         _, _, chiT = wl.chi_and_JT("ss", psi, tgt)
         eps_new, ga, psiT1 = eng.iteration(eps, chiT, S, lam)
-    X = np.empty((NT + 1, K, 10), complex)
+        again = eng.iteration(eps, chiT, S, lam)
+        assert np.array_equal(again[0], eps_new)
+    X = np.empty((NT + 1, K, N), complex)
     X[NT] = chiT
     for n in range(NT - 1, -1, -1):
-        U = o.step_propagator(H0, Hc, amp(eps[:, n]), tl[n + 1] - tl[n])
-        X[n] = X[n + 1] @ U.conj()      # chi <- U^dagger chi
+        X[n] = X[n + 1] @ Us[n].conj()      # chi <- U^dagger chi
     psi, eps_o, ga_o = psi0.copy(), eps.copy(), np.zeros(L)
     for n in range(NT):
         for l in range(L):
-            du = sum(np.vdot(X[n, k], fp(l, eps[l, n]) * (Hc[l] @ psi[k])).imag for k in range(K))
+            du = fp(l, eps[l, n]) * np.sum(np.einsum("ki,ki->k", X[n].conj(), psi @ Hc[l].T).imag)
             eps_o[l, n] = eps[l, n] + S[l, n] / lam[l] * du
             ga_o[l] += S[l, n] / lam[l] * du * du * (tl[n + 1] - tl[n])
         psi = psi @ o.step_propagator(H0, Hc, amp(eps_o[:, n]), tl[n + 1] - tl[n]).T

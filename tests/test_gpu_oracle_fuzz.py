@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed", [31, 32])
+@pytest.mark.parametrize("seed", [31, pytest.param(32, marks=pytest.mark.soak)])
 def test_random_problems_against_the_oracle(seed):
     e = dict(os.environ)
     e["ORACLE_FUZZ_NMAX"] = "130"
@@ -20,6 +20,7 @@ def test_random_problems_against_the_oracle(seed):
     assert r.returncode == 0 and "oracle_fuzz: 0 problem(s) in 30 shapes" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+@pytest.mark.soak
 def test_device_list_handles_in_a_process_that_has_seen_every_kind_of_handle():
     """Round 4: with ORACLE_FUZZ_DEVLIST every handle drives two shards on the one GPU.  This sequence (seed 8) used to lose partial
     sums of the per-step exchange in three or four of its 42 shapes -- KR_ERR_TIMEOUT at step 0, once a wrong forward sweep, once a GPU

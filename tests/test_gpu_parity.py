@@ -546,7 +546,7 @@ def test_c4_and_c5_shapes_short_grid(oracle_c):
     assert info["rowsplit_R"] == 8 and info["KT"] == 2 and info["workgroups"] == 256     # round 3: pair mode (two trajectories per group of 8)
 
 
-@pytest.mark.parametrize("case", ["liouvillian", "hermitian_substeps", "n130", "odd_k", "np128_local", "np128"])
+@pytest.mark.parametrize("case", ["liouvillian", pytest.param("hermitian_substeps", marks=pytest.mark.soak), "n130", pytest.param("odd_k", marks=pytest.mark.soak), "np128_local", "np128"])
 def test_rowsplit_pair_mode_agrees_with_single_mode_and_oracle(oracle_c, monkeypatch, case):
     """Row-split PAIR mode (kr_device_rowsplit2.h, round 3): groups of 2R workgroups interleave TWO trajectories (one's all-gather
     behind the other's row-dot, H(eps) and the control block resident) where the single mode would leave 64 rows per workgroup.

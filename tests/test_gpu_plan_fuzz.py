@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("env,seed", [({}, 11), ({"FUZZ_MAXWG": "64,100"}, 12), ({"FUZZ_NMAX": "64"}, 13)])
+@pytest.mark.parametrize("env,seed", [pytest.param({}, 11, marks=pytest.mark.soak), pytest.param({"FUZZ_MAXWG": "64,100"}, 12, marks=pytest.mark.soak), ({"FUZZ_NMAX": "64"}, 13)])
 def test_plans_agree_with_the_generic_kernels_on_random_shapes(env, seed):
     e = dict(os.environ)
     e.pop("KROTOV_HIP_GENERIC", None)

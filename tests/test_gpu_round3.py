@@ -498,7 +498,7 @@ def test_options_travel_in_kr_config(monkeypatch):
         assert "options" in str(ei.value) and bad in str(ei.value)
 
 
-@pytest.mark.parametrize("N,NT,K,L,R", [(300, 6, 3, 1, 64), (400, 4, 8, 2, 32), (512, 3, 2, 1, 64), (260, 34, 4, 2, 64), (280, 4, 3, 4, 64)])
+@pytest.mark.parametrize("N,NT,K,L,R", [(300, 6, 3, 1, 64), (400, 4, 8, 2, 32), pytest.param(512, 3, 2, 1, 64, marks=pytest.mark.soak), (260, 34, 4, 2, 64), (280, 4, 3, 4, 64)])
 def test_state_dimension_up_to_512_on_the_rowsplit_kernels(oracle_c, N, NT, K, L, R):
     """256 < N <= 512 (round 3): the single-mode row-split kernels with NP = 512 -- 64 or 32 workgroups per trajectory, 8 or 16 rows
     each, the all-gather polled by two waves -- instead of the generic multi-pass kernels (N = 512, K = 4: 14.6 / 19 us per step
@@ -514,8 +514,9 @@ def test_state_dimension_up_to_512_on_the_rowsplit_kernels(oracle_c, N, NT, K, L
     assert info["generic_known"] == 0 and info["generic_update"] == 0, info
 
 
-def test_state_dimension_above_256_with_more_trajectories(oracle_c):
-    """More trajectories than one NP = 512 / 1024 row-split launch carries (round 3).  The KNOWN-pulse sweeps run the row-split kernel
+@pytest.mark.parametrize("full", [False, pytest.param(True, marks=pytest.mark.soak)], ids=["one_shape_per_family", "all_shapes"])
+def test_state_dimension_above_256_with_more_trajectories(oracle_c, full):
+    """(round 5: the default selection runs one or two shapes per kernel family, the whole list is a soak leg.)  More trajectories than one NP = 512 / 1024 row-split launch carries (round 3).  The KNOWN-pulse sweeps run the row-split kernel
     in batches of trajectories (independent launches); the update sweep runs kr_rowsplit_turns_update -- every group of workgroups
     carries up to 16 trajectories in turn, H(eps) resident once, one exchange per step (N = 512, K = 32: 79 / 103 us per step against
     ~6 / 1.5 ms on the generic kernels) -- or, beyond 16 turns or with per-trajectory generators, the stepped
@@ -525,16 +526,16 @@ def test_state_dimension_above_256_with_more_trajectories(oracle_c):
     # turns (264: across a rebuild of H(eps); 520 with 8: a multiple of 8 trajectories on TWO groups -- the one-XCD layout of the
     # workgroup ids goes by the groups of a launch, not by the trajectories)
     # ((600, 2, 3, 2): NP = 1024 with two controls in two turns -- kr_rowsplit_turns_update<1024, 8, 2>, round 4)
-    for (N, NT, K, L, Kp) in [(300, 4, 20, 1, 24), (264, 34, 9, 2, 16), (520, 2, 3, 1, 4), (400, 3, 70, 2, 72), (516, 2, 8, 1, 8), (600, 2, 3, 2, 4)]:
+    for (N, NT, K, L, Kp) in [(300, 4, 20, 1, 24), (264, 34, 9, 2, 16), (520, 2, 3, 1, 4), (400, 3, 70, 2, 72), (516, 2, 8, 1, 8), (600, 2, 3, 2, 4)][(0 if full else 1):(6 if full else 3)]:
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=(N == 264))
         assert info["generic_known"] == 0 and info["generic_update"] == 0 and info["K_padded"] == Kp and info["workgroups"] == 256, info
     # 128 < N <= 256 with two controls and more than 64 trajectories: turns in groups of 8 workgroups instead of the streamed kernels
-    for (N, NT, K, L, Kp) in [(256, 36, 128, 2, 128), (200, 4, 70, 2, 96), (160, 3, 250, 2, 256)]:
+    for (N, NT, K, L, Kp) in [(256, 36, 128, 2, 128), (200, 4, 70, 2, 96), (160, 3, 250, 2, 256)][(0 if full else 1):(3 if full else 2)]:
         p = wl.dense_problem(N, NT, K, L, 7800 + N, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=(N == 200))
         assert info["NP"] == 256 and info["rowsplit_R"] == 8 and info["generic_update"] == 0 and info["K_padded"] == Kp, info
-    for (K, Kp) in [(9, 12), (16, 16)]:                                            # three controls: 8 rows per workgroup, 4 trajectories at once, 3 / 4 turns
+    for (K, Kp) in [(9, 12), (16, 16)][:(2 if full else 1)]:                       # three controls: 8 rows per workgroup, 4 trajectories at once, 3 / 4 turns
         p = wl.dense_problem(264, 4, K, 3, 7800 + 264 + K, 0.02, 2.0)
         info = tp._run_case(oracle_c, p, check_storage=False)
         assert info["generic_update"] == 0 and info["rowsplit_R"] == 64 and info["K_padded"] == Kp, info
@@ -548,7 +549,7 @@ def test_state_dimension_above_256_with_more_trajectories(oracle_c):
         assert info["generic_known"] == 1 and info["generic_update"] == 1, info
 
 
-@pytest.mark.parametrize("N,NT,K,L", [(640, 4, 2, 1), (1024, 3, 1, 2), (520, 36, 2, 2)])
+@pytest.mark.parametrize("N,NT,K,L", [(640, 4, 2, 1), (1024, 3, 1, 2), pytest.param(520, 36, 2, 2, marks=pytest.mark.soak)])
 def test_state_dimension_up_to_1024_on_the_rowsplit_kernels(N, NT, K, L):
     """512 < N <= 1024 (round 3): NP = 1024, 128 workgroups per trajectory with 8 rows each, four polling waves in the all-gather, at
     most two trajectories.  Against the serial restatement on the NumPy oracle's exact step propagator (the C oracle's plain-loop

@@ -219,3 +219,22 @@ def test_blocks_of_time_without_forward_storage_and_inside_an_iteration(oracle_c
         eps_new, ga, psiT1 = eng.iteration(p["eps"], chiT, p["S"], p["lam"])
     eps_o, ga_o, psiT1_o, _, _ = oracle_c.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT, mode=1, nthreads=8)
     assert _rel(eps_new, eps_o) < 1e-10 and _rel(ga, ga_o) < 1e-9 and np.max(np.abs(psiT1 - psiT1_o)) < 1e-9
+
+
+@pytest.mark.parametrize("shape", [(300, 4, 20, 1), (130, 5, 40, 1)], ids=["batched_known_sweeps_np512", "pair_np256"])
+def test_rowsplit_coherence_check_on_another_tile_and_on_the_batch_path(shape):
+    """The planted fault of round 4 sat in workgroup 1 (tile 0) of a single launch.  RS_FAULT=w now names the workgroup: w = R + 1 is a
+    member of tile 1, and with more trajectories than one launch carries the known-pulse sweeps run in BATCHES of launches, each with
+    its own check over its own tiles (rowsplit_postlaunch) -- the fault must be found there too, with the tile in the message."""
+    N, NT, K, L = shape
+    p = wl.dense_problem(N, NT, K, L, 5701, 0.02, 2.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        R = eng.info()["rowsplit_R"]
+        assert R > 1, eng.plan()
+        eng.set_initial_states(p["psi0"])
+        eng.forward(p["eps"])
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, options={"RS_FAULT": R + 1}) as eng:
+        eng.set_initial_states(p["psi0"])
+        with pytest.raises(kr.KrotovHipError) as ei:
+            eng.forward(p["eps"])
+        assert ei.value.code == capi.KR_ERR_INTERNAL and "share trajectory tile 1 " in str(ei.value), str(ei.value)

@@ -114,3 +114,19 @@ def test_every_ccall_matches_a_prototype_of_the_header():
     # the hot path and its error channel are bound
     for must in ("kr_create", "kr_destroy", "kr_last_error", "kr_set_initial_states", "kr_forward", "kr_iteration", "kr_read_storage"):
         assert must in seen, must
+
+
+def test_the_shim_replays_the_per_step_propagation_callbacks():
+    """The reference fires `wrk.fw_prop_kwargs[k][:callback]` / `wrk.bw_prop_kwargs[k][:callback]` after every prop_step!
+    (/root/reference/src/optimize.jl:258-262, 310-314, 362-366).  The shim must not drop them silently: it replays them from
+    kr_read_storage after the initial sweep and after every iteration -- backward sweep first, then the update sweep --, as the
+    Python mirror does (krotov.jl_amd/optimize.py: _replay_prop_callbacks)."""
+    assert "fw_prop_kwargs" in SHIM and "bw_prop_kwargs" in SHIM and ":callback" in SHIM and ":observables" in SHIM
+    body = SHIM[SHIM.index("function replay_prop_callbacks!"):]
+    body = body[:body.index("\nend\n")]
+    assert "read_storage(eng, which, k, slot)" in body and "cb(p, observables)" in body
+    assert "eng.NT:-1:1" in body and "2:eng.NT+1" in body          # backward: slots N_T .. 1; forward: slots 2 .. N_T + 1 (1-based)
+    init = SHIM[SHIM.index("function initial_fw_prop!"):SHIM.index("function iteration!")]
+    assert "replay_prop_callbacks!(eng, wrk, :fw)" in init
+    it = SHIM[SHIM.index("function iteration!"):SHIM.index("# ---- 3.")]
+    assert it.index("replay_prop_callbacks!(eng, wrk, :bw)") < it.index("replay_prop_callbacks!(eng, wrk, :fw)")

@@ -14,7 +14,10 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 p = wl.config(cfg)
 K, N = p["psi0"].shape
 L, NT = p["eps"].shape
-eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K)
+kw = {}
+if os.environ.get("TIME_SWEEPS_POLY"):   # non-linear controls: f_l(x) = x + x^2 / 2 (+ x^3 for the second control)
+    kw["control_poly"] = np.array([[0.0, 1.0, 0.5, 0.0], [0.0, 1.0, 0.5, 1.0], [0.0, 1.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]][:L])
+eng = kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, **kw)
 eng.set_initial_states(p["psi0"])
 psiT = eng.forward(p["eps"])
 _, JT, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
