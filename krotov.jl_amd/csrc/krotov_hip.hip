@@ -489,15 +489,19 @@ __global__ __launch_bounds__(256) void kr_poly_eval(const double *eps, const dou
 
 __global__ __launch_bounds__(256) void kr_pulse_finish(const double *eps_guess, const double *alpha, const double *fprime, const double *dulog, double *eps_new, int P, int L,
                                                        int LMAX, int NT, int check, unsigned *status) {
+    // blockIdx.y: a slice of the workgroups' logs (a first version walked all P logs from every thread: 256 dependent-free but
+    // serial loads per thread on eight workgroups -- 112 us at C3, 2 % of the iteration)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)L * NT) return;
     const int l = (int)(i / NT), n = (int)(i % NT);
     const double du = dulog[(size_t)n * LMAX + l];
-    eps_new[i] = __dadd_rn(eps_guess[i], __dmul_rn(alpha[i], fprime ? __dmul_rn(fprime[i], du) : du));   // (fprime: mu_l = f_l'(eps_guess) H_l, non-linear controls)
+    if (blockIdx.y == 0)
+        eps_new[i] = __dadd_rn(eps_guess[i], __dmul_rn(alpha[i], fprime ? __dmul_rn(fprime[i], du) : du));   // (fprime: mu_l = f_l'(eps_guess) H_l, non-linear controls)
     if (!check) return;
     const long long ref = __double_as_longlong(du);
+    const int per = (P + (int)gridDim.y - 1) / (int)gridDim.y, w0 = max(1, (int)blockIdx.y * per), w1 = min(P, ((int)blockIdx.y + 1) * per);
     int who = 0;
-    for (int w = 1; w < P; ++w) if (__double_as_longlong(dulog[((size_t)w * NT + n) * LMAX + l]) != ref && who == 0) who = w;
+    for (int w = w0; w < w1; ++w) if (__double_as_longlong(dulog[((size_t)w * NT + n) * LMAX + l]) != ref && who == 0) who = w;
     if (who && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 8u; status[2] = (unsigned)who; status[3] = (unsigned)i; }
 }
 
@@ -2206,7 +2210,8 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     if (rc) return rc;
     if (a.dulog && !calib_steps) {   // eps_new from workgroup 0's totals; every workgroup gathered the same totals in every step (~5 us)
         const size_t n = (size_t)h->cfg.L * h->cfg.NT;
-        hipLaunchKernelGGL(kr_pulse_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, eps_guess_dev, (const double *)h->S_d, a.fprime_g, (const double *)a.dulog,
+        const unsigned slices = h->pulse_check ? (unsigned)std::max(1, std::min(64, h->P / 4)) : 1u;
+        hipLaunchKernelGGL(kr_pulse_finish, dim3((unsigned)((n + 255) / 256), slices), dim3(256), 0, h->stream, eps_guess_dev, (const double *)h->S_d, a.fprime_g, (const double *)a.dulog,
                            eps_new_dev, h->P, h->cfg.L, h->LMAXv, h->cfg.NT, h->pulse_check ? 1 : 0, h->status_d);
         HIPCHK(h, hipGetLastError());
     }

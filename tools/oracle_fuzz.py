@@ -9,7 +9,9 @@ the pulses' rounding hides) to 1e-8 of its largest value, the running integral t
     ORACLE_FUZZ_DEVCHAIN=1: the two iterations also as one device-resident chain (kr_iteration_functional_dev);
     ORACLE_FUZZ_KBIG=1: most shapes at N <= 64 with 300 ... 5000 trajectories;
     ORACLE_FUZZ_METHODS=1: most shapes with prop_method = Chebyshev / Newton or the generic Taylor kernels forced;
-    ORACLE_FUZZ_HARD=1: half the shapes with ||H dt|| up to ~6 -- sub-stepping --, many with lambda_a / 50 -- large updates)"""
+    ORACLE_FUZZ_HARD=1: half the shapes with ||H dt|| up to ~6 -- sub-stepping --, many with lambda_a / 50 -- large updates;
+    ORACLE_FUZZ_TBLOCK=1: known-pulse sweeps in blocks of 2-5 time steps wherever the plan allows them (32 < N <= 64, N_T >= 2 S);
+    ORACLE_FUZZ_NS=33,48,64: draw N from this list only)"""
 import os
 import sys
 import time
@@ -30,6 +32,8 @@ for it in range(count):
     NS = [1, 2, 3, 5, 8, 9, 16, 17, 24, 32, 33, 48, 64, 65, 80, 100, 128, 130, 160, 200, 256, 257, 300]
     if os.environ.get("ORACLE_FUZZ_NMAX"):   # (the oracle's exact propagators cost seconds per shape at N >= 200: the test suite stays below)
         NS = [n for n in NS if n <= int(os.environ["ORACLE_FUZZ_NMAX"])]
+    if os.environ.get("ORACLE_FUZZ_NS"):
+        NS = [int(x) for x in os.environ["ORACLE_FUZZ_NS"].split(",")]
     if os.environ.get("ORACLE_FUZZ_NMIN"):   # (large state dimensions only: the row-split kernels of N > 128)
         NS = [n for n in NS if n >= int(os.environ["ORACLE_FUZZ_NMIN"])]
     N = int(rng.choice(NS))
@@ -131,6 +135,10 @@ for it in range(count):
             else:
                 kw["prop_method"] = kr._capi.KR_PROP_CHEBY if m == "cheby" else kr._capi.KR_PROP_NEWTON
             tag += " " + m
+        if os.environ.get("ORACLE_FUZZ_TBLOCK") and "options" not in kw:
+            # the known-pulse sweeps in blocks of time (32 < N <= 64) also on the fuzzer's short grids: blocks of 2-5 steps from 4 intervals on
+            kw["options"] = {"TBLOCK": int(rng.choice([2, 3, 4, 5])), "TBLOCK_MIN_NT": 4}
+            tag += " tblock%d" % kw["options"]["TBLOCK"]
         if os.environ.get("ORACLE_FUZZ_DEVLIST") and K >= 2:
             # ONE handle with a device list that names the GPU twice: two shards (library threads, peer-pointer mailboxes) share it --
             # the inter-GPU exchange of the update sweep on random shapes
