@@ -214,6 +214,8 @@ hipError_t kr_launch_rs1024(int lmax, int nr, int kind, int grid, hipStream_t s,
 // known-pulse sweeps in blocks of time (kr_device_tblock.h, NP = 64): kind 0 = block propagators into Pout (grid = generators x blocks),
 // kind 1 = all blocks in parallel (grid = blocks x items)
 hipError_t kr_launch_tblock(int kind, int grid, hipStream_t s, const KrSweepArgs *a, double2 *Pout);
+// ... and the block propagators as a tree of pairwise products, one level per launch (blocks of 2^p steps)
+hipError_t kr_launch_tbpair(int generators, int n_in, int level0, int final, hipStream_t s, const KrSweepArgs *a, const double2 *in, double2 *out);
 
 // generic (multi-pass) kernels (kr_device_generic.h)
 struct KrGenArgs {

@@ -114,6 +114,99 @@ __global__ __launch_bounds__(256, 1) void kr_tb_products(const KrSweepArgs a, do
 #undef KR_TBI
 }
 
+// ---- (ii) as a tree of pairwise products (S a power of two) ------------------------------------------------------------------
+// One level: out[j] = in[2 j + 1] in[2 j] (sweep order: the later factor on the left), both in fragment order; a last matrix without a
+// partner is copied.  grid = generators x ceil(n_in / 2).  log2(S) dependent launches of ~8 us replace the chain of S - 1 products
+// inside one workgroup (which also leaves half the chip idle at S = 8): S = 16 costs what S = 8 cost, and the sequential sweep (iii)
+// over the block boundaries -- a chain of latencies -- halves.  `final`: the level's output feeds the sequential apply kernel and is
+// written in ITS operand order (a.u_layout 0 / 1); otherwise fragment order for the next level.
+template <int DUMMY>
+__global__ __launch_bounds__(256, 1) void kr_tb_pair(const KrSweepArgs a, const double2 *__restrict__ in, double2 *__restrict__ out, const int n_in, const int level0,
+                                                     const int final) {
+    extern __shared__ __attribute__((aligned(16))) double kr_tbq_lds[];   // planes [re | im][64][KR_TB_YS] of the right factor, then of the product
+#define KR_TQR (kr_tbq_lds)
+#define KR_TQI (kr_tbq_lds + 64 * KR_TB_YS)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int n_out = (n_in + 1) / 2;
+    const int gen = blockIdx.x / n_out, j = blockIdx.x % n_out;
+    const int NT = a.tb_NT;
+    const int row = 16 * w + li;
+    // level 0 reads the step propagators in SWEEP order (backward sweeps run down the grid); later levels read what this kernel wrote
+    auto mat = [&](const int idx) {
+        const int n = level0 ? ((a.dir > 0) ? idx : (NT - 1 - idx)) : idx;
+        return in + ((size_t)gen * n_in + n) * 4096;
+    };
+    const bool paired = (2 * j + 1) < n_in;
+    {   // right factor (or the lone matrix) -> planes
+        const double2 *F = mat(2 * j) + (size_t)(16 * w) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const double2 u = F[(size_t)t * 64];
+            KR_TQR[row * KR_TB_YS + 4 * t + lk] = u.x;
+            KR_TQI[row * KR_TB_YS + 4 * t + lk] = u.y;
+        }
+    }
+    __syncthreads();
+    if (paired) {
+        double Ar[16], Ai[16], As[16];
+        const double2 *F = mat(2 * j + 1) + (size_t)(16 * w) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const double2 u = F[(size_t)t * 64]; Ar[t] = u.x; Ai[t] = u.y; As[t] = u.x + u.y; }
+        kr_tb_d4 dr[4], di[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            kr_tb_d4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0}, pc = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const double br = KR_TQR[(4 * t + lk) * KR_TB_YS + 16 * ct + li];
+                const double bi = KR_TQI[(4 * t + lk) * KR_TB_YS + 16 * ct + li];
+                const double bs = br + bi;
+                pa = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[t], br, pa, 0, 0, 0);
+                pb = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[t], bi, pb, 0, 0, 0);
+                pc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[t], bs, pc, 0, 0, 0);
+            }
+            dr[ct] = pa - pb;
+            di[ct] = (pc - pa) - pb;
+        }
+        __syncthreads();   // every wave has read the right factor: the planes take the product (D layout positions)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = 16 * w + lk + 4 * r, ocol = 16 * ct + li;
+                KR_TQR[orow * KR_TB_YS + ocol] = dr[ct][r];
+                KR_TQI[orow * KR_TB_YS + ocol] = di[ct][r];
+            }
+        __syncthreads();
+    }
+    double2 *Pn = out + ((size_t)gen * n_out + j) * 4096;
+    if (!final) {   // fragment order: [(16 w' + t) * 64 + lane] = {re, im} of M[16 w' + (lane & 15)][4 t + (lane >> 4)]
+        for (int e = tid; e < 4096; e += 256) {
+            const int l = e & 63, t = (e >> 6) & 15, wt = e >> 10;
+            const int r = 16 * wt + (l & 15), cc = 4 * t + (l >> 4);
+            Pn[e] = make_double2(KR_TQR[r * KR_TB_YS + cc], KR_TQI[r * KR_TB_YS + cc]);
+        }
+    } else if (a.u_layout == 1) {   // MFMA A operands of kr_mf_apply_sweep: {-Ui, Ur}, lane order (f0, blk, f2)
+        for (int e = tid; e < 4096; e += 256) {
+            const int l = e & 63, sl = (e >> 6) & 15, wv = e >> 10;
+            const int r = 16 * wv + 4 * ((l >> 2) & 3) + (l & 3), cc = 4 * ((4 * wv + sl) & 15) + (l >> 4);
+            Pn[e] = make_double2(-KR_TQI[r * KR_TB_YS + cc], KR_TQR[r * KR_TB_YS + cc]);
+        }
+    } else {                        // thread-major pack of kr_sweep_apply
+        constexpr int JQ_A = KR_APPLY_JQ64, JS_A = 64 / JQ_A, RT_A = 64 * JQ_A;
+        for (int t2 = tid; t2 < RT_A; t2 += 256) {
+            const int i = t2 / JQ_A, jq = t2 % JQ_A;
+#pragma unroll
+            for (int jj = 0; jj < JS_A; ++jj) {
+                const int c = jq * JS_A + jj;
+                Pn[(size_t)jj * RT_A + t2] = make_double2(KR_TQR[i * KR_TB_YS + c], KR_TQI[i * KR_TB_YS + c]);
+            }
+        }
+    }
+#undef KR_TQR
+#undef KR_TQI
+}
+
 // ---- (iv) all blocks in parallel --------------------------------------------------------------------------------------
 // grid = NB x items; workgroup (b, item) carries trajectories [k0, k0 + cnt) (cnt <= 64, one generator) through the steps of block b.
 template <int DUMMY>
@@ -218,6 +311,15 @@ __global__ __launch_bounds__(256, 1) void kr_tb_apply(const KrSweepArgs a) {
         for (int t = 0; t < 16; ++t)
             if (4 * t + lk < N) dst[4 * t + lk] = src[4 * t + lk];
     }
+}
+
+// one level of the tree of pairwise products: n_in matrices per generator in `in` -> ceil(n_in / 2) in `out`
+static inline hipError_t kr_launch_tbpair_impl(int generators, int n_in, int level0, int final, hipStream_t s, const KrSweepArgs *a, const double2 *in, double2 *out) {
+    constexpr size_t lds = (size_t)2 * 64 * KR_TB_YS * sizeof(double);
+    hipError_t e = kr_raise_dynamic_lds((const void *)kr_tb_pair<0>, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kr_tb_pair<0>, dim3(generators * ((n_in + 1) / 2)), dim3(256), lds, s, *a, in, out, n_in, level0, final);
+    return hipGetLastError();
 }
 
 // kind: 0 block propagators (lds: two plane pairs), 1 parallel apply (lds: two U buffers)

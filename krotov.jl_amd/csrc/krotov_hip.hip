@@ -90,7 +90,8 @@ struct kr_handle {
     // known-pulse sweeps in blocks of time (kr_device_tblock.h, NP = 64): tb_S steps per block (0: sequential apply sweep), block
     // propagators [G][NB][4096], states at the block boundaries [NB + 1][Kp][N], the trajectory ranges a workgroup carries
     int tb_S = 0, tb_NB = 0, tb_nitems = 0;
-    double2 *tb_P_d = nullptr, *tb_bound_d = nullptr;
+    bool tb_tree = false;      // block propagators as a tree of pairwise products (tb_S a power of two), two ping-pong buffers of N_T / 2 matrices
+    double2 *tb_P_d = nullptr, *tb_bound_d = nullptr, *tb_T_d[2] = {nullptr, nullptr};
     int *tb_items_d = nullptr;
     bool precomp = false;
     bool use_mfma = true;
@@ -269,7 +270,7 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
 static const char *const kr_option_names[] = {
     "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
     "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "MAIL_SELFTEST", "MAIL_FAULT", "PACK_CHECK", "PACK_FAULT", "POLL_DELAY", "PRECOMP", "PULSE_CHECK", "PULSE_FAULT", "RCCL_CACHE", "ROWSPLIT",
-    "RS512", "RS_BATCH", "RS_FAULT", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "SHARD_SKEW_MS", "STAMPS", "TBLOCK", "TBLOCK_MIN_NT", "UC_POOL", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY", "ZERO_KERNEL", "ZERO_SYNC"};
+    "RS512", "RS_BATCH", "RS_FAULT", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "SHARD_SKEW_MS", "STAMPS", "TBLOCK", "TBLOCK_MIN_NT", "TBLOCK_TREE", "UC_POOL", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY", "ZERO_KERNEL", "ZERO_SYNC"};
 static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
     out.clear();
     if (!text) return true;
@@ -1012,7 +1013,7 @@ static void free_all(kr_handle *h) {
     void *ptrs[] = {h->Hpack_fw, h->Hpack_bw, h->pack_words_d, h->dt_d, h->eps_a, h->eps_b, h->S_d, h->lambda_d, h->gint_d, h->psi0_d,
                     h->tgt_d, h->psiT_d, h->chiT_d, h->X_d, h->Phi_d, h->tau_d, h->tausum_d, h->status_d, h->debug_d, h->U_d, h->wg_gen_d, h->nrm_d, h->present_d, h->gmail_d, h->Hdense_fw, h->Hcol_fw, h->Hcol_bw, h->Heps_d, h->econ_d, h->skw_d,
                     h->tile_gen_d, h->nrm_gen_d, h->partial_d, h->du_local_d, h->du_total_d, h->ptab_d, h->erange_d, h->poly_d, h->rs_scratch_d,
-                    h->tb_P_d, h->tb_bound_d, h->tb_items_d, h->dulog_d, h->poly3_d, h->amp_d, h->fprime_d};
+                    h->tb_P_d, h->tb_bound_d, h->tb_items_d, h->dulog_d, h->poly3_d, h->amp_d, h->fprime_d, h->tb_T_d[0], h->tb_T_d[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->peers_connected && !h->peers_in_process)   // (cached mappings stay open: ipc_open)
         for (int r = 0; r < h->cfg.world; ++r)
@@ -1465,28 +1466,46 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         if (h->precomp) CHK(dalloc(&h->U_d, (size_t)G * NT * NP * NP));
         // ... and in blocks of time (round 5): NP = 64 with the matrix-core propagator build, grids long enough for the two extra
         // passes to pay (TBLOCK_MIN_NT), the boundary buffer within a budget.  KROTOV_HIP_TBLOCK = steps per block, 0 = off.
-        const int S = opt_int(h, "TBLOCK", 8);
-        if (h->precomp && NP == 64 && h->use_mfma && S >= 2 && S <= 64 && NT >= opt_int(h, "TBLOCK_MIN_NT", 64) && NT >= 2 * S) {
-            const int NB = (NT + S - 1) / S;
-            const size_t bbytes = (size_t)(NB + 1) * h->Kp * N * sizeof(double2);
-            if (bbytes <= ((size_t)4 << 30)) {
-                h->tb_S = S; h->tb_NB = NB;
-                CHK(dalloc(&h->tb_P_d, (size_t)G * NB * 4096));
-                CHK(dalloc(&h->tb_bound_d, (size_t)(NB + 1) * h->Kp * N));
-                // items: runs of internal slots with one generator (the slots are grouped by generator, every group padded to whole
-                // tiles with zero trajectories), cut into pieces of at most 64
-                std::vector<int> items;
-                const int tiles = (int)wg_gen.size(), ktile = h->KTILE;
-                int t0 = 0;
-                while (t0 < tiles) {
-                    int t1 = t0;
-                    while (t1 < tiles && wg_gen[t1] == wg_gen[t0]) ++t1;
-                    for (int k0 = t0 * ktile; k0 < t1 * ktile; k0 += 64) { items.push_back(k0); items.push_back(std::min(64, t1 * ktile - k0)); items.push_back(wg_gen[t0]); items.push_back(0); }
-                    t0 = t1;
+        // Steps per block: KROTOV_HIP_TBLOCK (0 = off), or -- default -- by the shape: the parallel pass (iv) wants at least one workgroup
+        // per CU (blocks x pieces of <= 64 trajectories), the sequential pass (iii) as few blocks as possible.  Measured, backward sweep
+        // [ms] at S = 8 / 16 / 32 with the tree of products: C3 (4 pieces) 0.50 / 0.46 / 0.57, C4 (16 pieces) 1.01 / 0.94 / 0.92
+        // (profiles/r05_tb_tree.log).
+        if (h->precomp && NP == 64 && h->use_mfma && NT >= opt_int(h, "TBLOCK_MIN_NT", 64)) {
+            // pieces: runs of internal slots with one generator (the slots are grouped by generator, every group padded to whole tiles
+            // with zero trajectories), cut into pieces of at most 64
+            std::vector<int> items;
+            const int tiles = (int)wg_gen.size(), ktile = h->KTILE;
+            int t0 = 0;
+            while (t0 < tiles) {
+                int t1 = t0;
+                while (t1 < tiles && wg_gen[t1] == wg_gen[t0]) ++t1;
+                for (int k0 = t0 * ktile; k0 < t1 * ktile; k0 += 64) { items.push_back(k0); items.push_back(std::min(64, t1 * ktile - k0)); items.push_back(wg_gen[t0]); items.push_back(0); }
+                t0 = t1;
+            }
+            const int nitems = (int)items.size() / 4;
+            int S = opt_int(h, "TBLOCK", -1);
+            if (S < 0) {
+                hipDeviceProp_t prop;
+                CHK(hipGetDeviceProperties(&prop, h->device));
+                const int cus = prop.multiProcessorCount;
+                auto wgs = [&](int s_) { return (long long)((NT + s_ - 1) / s_) * nitems; };
+                S = (wgs(32) >= cus) ? 32 : (wgs(16) * 2 >= cus) ? 16 : 8;
+            }
+            if (S >= 2 && S <= 64 && NT >= 2 * S) {
+                const int NB = (NT + S - 1) / S;
+                const size_t bbytes = (size_t)(NB + 1) * h->Kp * N * sizeof(double2);
+                if (bbytes <= ((size_t)4 << 30)) {
+                    h->tb_S = S; h->tb_NB = NB; h->tb_nitems = nitems;
+                    CHK(dalloc(&h->tb_P_d, (size_t)G * NB * 4096));
+                    h->tb_tree = (S & (S - 1)) == 0 && S >= 4 && opt_int(h, "TBLOCK_TREE", 1) != 0;
+                    if (h->tb_tree) {
+                        CHK(dalloc(&h->tb_T_d[0], (size_t)G * ((NT + 1) / 2) * 4096));
+                        CHK(dalloc(&h->tb_T_d[1], (size_t)G * ((NT + 3) / 4) * 4096));
+                    }
+                    CHK(dalloc(&h->tb_bound_d, (size_t)(NB + 1) * h->Kp * N));
+                    CHK(dalloc(&h->tb_items_d, items.size()));
+                    CHK(hipMemcpy(h->tb_items_d, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
                 }
-                h->tb_nitems = (int)items.size() / 4;
-                CHK(dalloc(&h->tb_items_d, items.size()));
-                CHK(hipMemcpy(h->tb_items_d, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
             }
         }
     }
@@ -2106,6 +2125,17 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
             // (ii) block propagators, in the operand order of the sequential kernel that consumes them
             KrSweepArgs pa = a;
             pa.tb_NT = h->cfg.NT; pa.tb_S = h->tb_S; pa.u_layout = mf_apply ? 1 : 0;
+            if (h->tb_tree) {   // log2(S) levels of pairwise products, the last one in the consumer's operand order
+                const double2 *in = h->U_d;
+                int n = h->cfg.NT, lev = 0;
+                for (int span = 1; span < h->tb_S; span *= 2, ++lev) {
+                    const bool last = (2 * span >= h->tb_S);
+                    double2 *out = last ? h->tb_P_d : h->tb_T_d[lev & 1];
+                    HIPCHK(h, kr_launch_tbpair(h->G, n, lev == 0 ? 1 : 0, last ? 1 : 0, h->stream, &pa, in, out));
+                    in = out;
+                    n = (n + 1) / 2;
+                }
+            } else
             HIPCHK(h, kr_launch_tblock(0, h->G * h->tb_NB, h->stream, &pa, h->tb_P_d));
             // (iii) states at the block boundaries: the sequential sweep over the block propagators, in sweep order (dir = +1:
             //       boundary b + 1 after block b), final states as before

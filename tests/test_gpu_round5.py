@@ -129,14 +129,15 @@ def _nonherm(p, rng, N):
     p["H0"] = p["H0"] - 1j * 0.05 * np.diag(rng.uniform(0, 1, N)) + 0.02 * rng.normal(size=(N, N))
 
 
-@pytest.mark.parametrize("case", ["c3_shape", "ragged_nonherm_grid", "n40_k70", "two_generators", "matrix_cores_k600", "few_k3", "blocks_of_5", "blocks_of_16"])
+@pytest.mark.parametrize("case", ["c3_shape", "ragged_nonherm_grid", "n40_k70", "two_generators", "matrix_cores_k600", "few_k3", "blocks_of_5", "blocks_of_8_chain", "blocks_of_4_tree", "blocks_of_32"])
 def test_known_pulse_sweeps_in_blocks_of_time_vs_oracle(case, oracle_c):
     """Round 5, kr_device_tblock.h: step propagators -> block propagators (matrix cores) -> sequential sweep over the block boundaries ->
     all blocks in parallel.  Forward storage (optimize.jl:254,263: slot n + 1), backward storage through the TRUE adjoint (optimize.jl:
     307,315: slot n; workspace.jl:69) and the final states against the C oracle at the tolerances of the sequential sweeps (states
     1e-11), for: C3's shape on a shorter grid, a ragged last block with a dissipative drift on a non-uniform grid, N < 64 with a
     trajectory count that fills neither a wave nor a workgroup, per-trajectory generators, the shapes whose sequential kernels run on
-    the matrix cores, three trajectories, other block lengths.  The sequential sweep (TBLOCK=0) must agree to rounding."""
+    the matrix cores, three trajectories, other block lengths, the block propagators as a tree of pairwise products (default, blocks of
+    16) or as a chain per block.  The sequential sweep (TBLOCK=0) must agree to rounding."""
     rng = np.random.default_rng(5500)
     opts, tg, G = {}, None, 1
     if case == "c3_shape":
@@ -154,9 +155,15 @@ def test_known_pulse_sweeps_in_blocks_of_time_vs_oracle(case, oracle_c):
     elif case == "blocks_of_5":
         N, NT, K, L = 33, 64, 20, 2
         opts["TBLOCK"] = 5
-    else:
+    elif case == "blocks_of_8_chain":      # (the default is a tree of pairwise products over blocks of 16 steps: here the chain of products per block)
         N, NT, K, L = 64, 67, 24, 1
-        opts["TBLOCK"] = 16
+        opts.update(TBLOCK=8, TBLOCK_TREE=0)
+    elif case == "blocks_of_4_tree":
+        N, NT, K, L = 50, 71, 130, 2
+        opts["TBLOCK"] = 4
+    else:
+        N, NT, K, L = 64, 150, 24, 1
+        opts["TBLOCK"] = 32
     p = wl.dense_problem(N, NT, K, L, 5501, 0.05, 2.0)
     if case in ("ragged_nonherm_grid", "blocks_of_5"):
         _nonherm(p, rng, N)
