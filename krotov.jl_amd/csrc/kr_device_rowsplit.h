@@ -430,6 +430,10 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
             }
             if (n + 1 < NT && row_ok) { const double2 c = a.X[(size_t)(n + 1) * slab + kbase + row]; cr = c.x; ci = c.y; }
             if (!kr_exchange<XL, NR, KR_RS_SCHED>(a, n, wg, owner, il, part, du, spart, stot)) return;
+            if (tid == 128 && a.dulog) {   // the totals this workgroup gathered, for kr_pulse_finish's comparison (kr_sweep_update, kr_device.h)
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) if (l < L) a.dulog[((size_t)wg * NT + n) * KR_LMAX_CAP + l] = (l == 0 && a.rs_fault == 1000 + wg && n == 1) ? -du[l] : du[l];
+            }
             KR_STAMP(tX)
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) {
@@ -667,6 +671,10 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
             __syncthreads();   // (the next set overwrites sx[0])
         }
         if (!kr_exchange<XL, NR, KR_RS_SCHED>(a, n, wg, owner, il, part, du, spart, stot)) return;
+        if (tid == 128 && a.dulog) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) if (l < L) a.dulog[((size_t)wg * NT + n) * KR_LMAX_CAP + l] = (l == 0 && a.rs_fault == 1000 + wg && n == 1) ? -du[l] : du[l];
+        }
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             if (l < L) {

@@ -545,6 +545,9 @@ kr_next_set:
             de = e - eg;
             const double ad = fabs(du[0]);
             gint = __dadd_rn(gint, __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dtn));
+            // (no log of the gathered totals here, unlike every other persistent update kernel: this kernel sits at 256 VGPRs with scratch, and
+            //  both placements of the one store -- lane 0 of wave 2 behind the exchange, or the eps_new store below redirected per workgroup
+            //  -- cost C5 1.4 % of the iteration, the second one through the KNOWN-pulse instantiation of this very template, 28.55 -> 29.12 ms)
             if (wg == 0 && tid == 0) a.eps_new[n] = e;
             // H(eps_new) = H(eps_g) + d eps H_1, in registers
 #pragma unroll

@@ -489,18 +489,19 @@ __global__ __launch_bounds__(256) void kr_poly_eval(const double *eps, const dou
 }
 
 __global__ __launch_bounds__(256) void kr_pulse_finish(const double *eps_guess, const double *alpha, const double *fprime, const double *dulog, double *eps_new, int P, int L,
-                                                       int LMAX, int NT, int check, unsigned *status) {
+                                                       int LMAX, int NT, int check, unsigned *status, int ref_wg) {
     // blockIdx.y: a slice of the workgroups' logs (a first version walked all P logs from every thread: 256 dependent-free but
     // serial loads per thread on eight workgroups -- 112 us at C3, 2 % of the iteration)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)L * NT) return;
     const int l = (int)(i / NT), n = (int)(i % NT);
-    const double du = dulog[(size_t)n * LMAX + l];
-    if (blockIdx.y == 0)
+    // (ref_wg: the workgroup whose log is the reference -- 0, or 1 where workgroup 0 spends its one store on the caller's eps_new: pair mode)
+    const double du = dulog[((size_t)ref_wg * NT + n) * LMAX + l];
+    if (blockIdx.y == 0 && eps_new)   // (row-split kernels write eps_new themselves and pass nullptr: comparison only)
         eps_new[i] = __dadd_rn(eps_guess[i], __dmul_rn(alpha[i], fprime ? __dmul_rn(fprime[i], du) : du));   // (fprime: mu_l = f_l'(eps_guess) H_l, non-linear controls)
     if (!check) return;
     const long long ref = __double_as_longlong(du);
-    const int per = (P + (int)gridDim.y - 1) / (int)gridDim.y, w0 = max(1, (int)blockIdx.y * per), w1 = min(P, ((int)blockIdx.y + 1) * per);
+    const int per = (P + (int)gridDim.y - 1) / (int)gridDim.y, w0 = max(ref_wg + 1, (int)blockIdx.y * per), w1 = min(P, ((int)blockIdx.y + 1) * per);
     int who = 0;
     for (int w = w0; w < w1; ++w) if (__double_as_longlong(dulog[((size_t)w * NT + n) * LMAX + l]) != ref && who == 0) who = w;
     if (who && atomicCAS(status, 0u, 1u) == 0u) { status[1] = 8u; status[2] = (unsigned)who; status[3] = (unsigned)i; }
@@ -1521,8 +1522,9 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
                                                             // one-XCD placement (kr_sweep_update)
     // (the generic update kernels do not use this mailbox: any number of tiles -- N = 8, K = 8193 used to fail here)
     if (!h->gen_update && (size_t)h->P * 4 > KR_MAIL_RSTRIDE) { fail(h, KR_ERR_UNSUPPORTED, "%d workgroups do not fit one mailbox replica", h->P); return bail(KR_ERR_UNSUPPORTED); }
-    h->pulse_check = opt_int(h, "PULSE_CHECK", 1) != 0 && !h->gen_update && !h->rowsplit && h->P > 1;
+    h->pulse_check = opt_int(h, "PULSE_CHECK", 1) != 0 && !h->gen_update && h->P > 1;
     if (!h->gen_update && !h->rowsplit) CHK(dalloc(&h->dulog_d, (size_t)h->P * NT * h->LMAXv));   // (eps_new is formed from workgroup 0's log whether the logs are compared or not)
+    else if (!h->gen_update && h->pulse_check && !h->rs_pair) CHK(dalloc(&h->dulog_d, (size_t)h->P * NT * KR_LMAX_CAP));   // (row-split kernels: comparison only, stride KR_LMAX_CAP; not the pair mode: kr_device_rowsplit2.h)
     // The mailbox of the per-step exchange, self-tested (kr_mail_selftest: the exchange's own store / poll pattern on both buffers and
     // all replicas, ~50 us): a block on which stores get lost or stay invisible to some XCDs -- seen for blocks that reuse the address
     // range of a freed uncached block, which this library no longer frees but another library of the process may -- is set aside and
@@ -1598,7 +1600,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
                  "integrity checks: operator-copy checksums %s, group coherence words %s, per-step totals of all workgroups compared %s, mailbox self-test %s%s%s%s",
                  h->cfg.N, h->NP, h->cfg.NT, h->cfg.K, h->Kp, h->cfg.L, h->G, h->cfg.rank, h->cfg.world, h->device, upd, h->P, h->KTILE, h->rs_turns > 0 ? h->rs_turns : h->sets,
                  h->wg_stride > 1 ? 1 : 0, h->rowsplit ? h->R : 1, h->herm ? 1 : 0, (h->econ || h->econ_gen) ? 1 : 0, h->poll_delay, known, exn[h->exchange & 3], (double)h->spin_ticks / 1e5,
-                 h->pack_words_d ? "on" : "off", (h->rowsplit && h->R > 1) ? "on" : "n/a", h->pulse_check ? "on" : "n/a",
+                 h->pack_words_d ? "on" : "off", (h->rowsplit && h->R > 1) ? "on" : "n/a", (h->pulse_check && h->dulog_d) ? "on" : "n/a",
                  (h->gen_update || opt_int(h, "MAIL_SELFTEST", 1) == 0) ? "off" : (h->quarantined ? "passed after setting blocks aside" : "passed"),
                  opt_int(h, "UC_POOL", 1) == 0 ? "; WARNING: UC_POOL=0 (diagnostics only): uncached mailboxes are freed again, and blocks that reuse their address range lose stores on this platform" : "",
                  h->plan_note.empty() ? "" : "; note: ", h->plan_note.c_str());
@@ -1746,7 +1748,7 @@ static void base_args(kr_handle *h, KrSweepArgs &a) {
     a.xcd_group = h->xcd_group ? 1 : 0;
     a.rs_sets = h->rs_sets;
     a.rs_fault = opt_int(h, "RS_FAULT", 0);
-    if (opt_int(h, "PULSE_FAULT", 0) != 0) a.rs_fault = 2;   // (tests: workgroup 1 folds a wrong pulse value into its coherence word at step 3)
+    if (opt_int(h, "PULSE_FAULT", 0) != 0) a.rs_fault = h->rowsplit ? 1001 : 2;   // (tests: workgroup 1 logs a wrong total at step 3 / step 1 of a row-split sweep)
     a.rs_scratch = h->rs_scratch_d;
     a.pack_stride = h->pack_stride;
     a.Hdense = h->Hdense_fw;
@@ -2241,8 +2243,14 @@ static int launch_update(kr_handle *h, const double *eps_guess_dev, double *eps_
     if (a.dulog && !calib_steps) {   // eps_new from workgroup 0's totals; every workgroup gathered the same totals in every step (~5 us)
         const size_t n = (size_t)h->cfg.L * h->cfg.NT;
         const unsigned slices = h->pulse_check ? (unsigned)std::max(1, std::min(64, h->P / 4)) : 1u;
+        if (h->rowsplit) {   // the row-split update kernels write eps_new themselves: the logs are only compared
+            hipLaunchKernelGGL(kr_pulse_finish, dim3((unsigned)((n + 255) / 256), slices), dim3(256), 0, h->stream, eps_guess_dev, (const double *)h->S_d, (const double *)nullptr,
+                               (const double *)a.dulog, (double *)nullptr, h->P, h->cfg.L, KR_LMAX_CAP, h->cfg.NT, 1, h->status_d, 0);
+            HIPCHK(h, hipGetLastError());
+            return KR_OK;
+        }
         hipLaunchKernelGGL(kr_pulse_finish, dim3((unsigned)((n + 255) / 256), slices), dim3(256), 0, h->stream, eps_guess_dev, (const double *)h->S_d, a.fprime_g, (const double *)a.dulog,
-                           eps_new_dev, h->P, h->cfg.L, h->LMAXv, h->cfg.NT, h->pulse_check ? 1 : 0, h->status_d);
+                           eps_new_dev, h->P, h->cfg.L, h->LMAXv, h->cfg.NT, h->pulse_check ? 1 : 0, h->status_d, 0);
         HIPCHK(h, hipGetLastError());
     }
     return KR_OK;
@@ -2339,7 +2347,7 @@ static int check_status(kr_handle *h) {
             return fail(h, KR_ERR_INTERNAL, "the %s generator pack on the device no longer matches the operators kr_create uploaded (checksum mismatch in front of a sweep): device memory was corrupted; results of this call are invalid -- create a new handle",
                         st[2] == 0 ? "forward" : st[2] == 1 ? "adjoint (backward-sweep)" : st[2] == 2 ? "dense (matrix-core)" : st[2] == 3 ? "column-major forward" : "column-major adjoint");
         if (st[1] == 8)
-            return fail(h, KR_ERR_INTERNAL, "update sweep: workgroup %u gathered other totals than workgroup 0 and formed another pulse value (control %u, step %u: a partial sum of the per-step exchange was lost or accepted stale in one workgroup's gather); results of this call are invalid",
+            return fail(h, KR_ERR_INTERNAL, "update sweep: workgroup %u gathered other totals than the reference workgroup and formed another pulse value (control %u, step %u: a partial sum of the per-step exchange was lost or accepted stale in one workgroup's gather); results of this call are invalid",
                         st[2], st[3] / (unsigned)h->cfg.NT, st[3] % (unsigned)h->cfg.NT);
         if (st[1] == 9)
             return fail(h, KR_ERR_INTERNAL, "mailbox self-test failed (workgroup %u, round %u): device memory of this process loses stores or hides them from some XCDs", st[2] & 0xffffu, (st[2] >> 16) & 0xffu);

@@ -39,6 +39,16 @@ def test_abi_version(lib):
     assert lib.kr_abi_version() == capi.KR_ABI_VERSION == 3
 
 
+def test_the_ipc_blob_is_sized_by_the_library(lib):
+    """kr_ipc_export hands out kr_ipc_handle_size() opaque bytes: the HIP IPC handle (64) plus, since round 5, the generation of the
+    exporter's pooled mailbox and a flag (16) -- every rank derives the tag base of a set of handles from all ranks' generations, so
+    that a late store of an earlier set cannot satisfy a poll of the set that recycled the block.  Callers must size their buffers
+    with the function (the Python binding does), never with a constant."""
+    assert lib.kr_ipc_handle_size() == 80
+    src = open(os.path.join(ROOT, "krotov.jl_amd", "engine.py")).read()
+    assert "kr_ipc_handle_size()" in src
+
+
 def test_a_v2_config_is_refused(lib):
     """ABI v3 gave two of v2's `reserved` words a meaning (spin_timeout_ms, the `options` pointer that kr_create dereferences): a v2
     caller that never zeroed them must be stopped by the version check, before anything reads those words."""

@@ -38,7 +38,7 @@ def test_pulse_coherence_words_find_a_planted_fault(shape, oracle_c):
         eng.forward(p["eps"])
         with pytest.raises(kr.KrotovHipError) as ei:
             eng.iteration(p["eps"], chiT, p["S"], p["lam"])
-        assert ei.value.code == capi.KR_ERR_INTERNAL and "workgroup 1 gathered other totals than workgroup 0" in str(ei.value), str(ei.value)
+        assert ei.value.code == capi.KR_ERR_INTERNAL and "gathered other totals than the reference workgroup" in str(ei.value), str(ei.value)
     with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, options={"PULSE_CHECK": 0, "PULSE_FAULT": 1}) as eng:   # check off: nothing posted, nothing found
         assert "per-step totals of all workgroups compared n/a" in eng.plan()
         eng.set_initial_states(p["psi0"])
@@ -245,3 +245,30 @@ def test_rowsplit_coherence_check_on_another_tile_and_on_the_batch_path(shape):
         with pytest.raises(kr.KrotovHipError) as ei:
             eng.forward(p["eps"])
         assert ei.value.code == capi.KR_ERR_INTERNAL and "share trajectory tile 1 " in str(ei.value), str(ei.value)
+
+
+@pytest.mark.parametrize("shape", [(100, 6, 6, 2), (300, 4, 12, 2)], ids=["single_np128", "turns_np512"])
+def test_rowsplit_update_sweeps_compare_the_workgroups_totals(shape, oracle_c):
+    """The row-split update kernels form eps_new per workgroup as well; their coherence words compare the copies of a trajectory's STATE
+    inside a group, which a wrong total in one member does not disturb.  Round 5: they log the totals they gathered like the N <= 64
+    kernels (kr_pulse_finish, comparison only -- these kernels still write eps_new themselves; not the pair mode, whose kernel sits at
+    the register limit: either placement of the store cost C5 1.4 %).  Clean run against the oracle; with
+    PULSE_FAULT workgroup 1 logs a wrong total at step 1 and the call fails with KR_ERR_INTERNAL."""
+    N, NT, K, L = shape
+    p = wl.dense_problem(N, NT, K, L, 5801, 0.02, 2.0)
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K) as eng:
+        info = eng.info()
+        assert info["rowsplit_R"] > 1 and info["generic_update"] == 0, eng.plan()
+        assert "per-step totals of all workgroups compared on" in eng.plan(), eng.plan()
+        eng.set_initial_states(p["psi0"])
+        psiT = eng.forward(p["eps"])
+        _, _, chiT = wl.chi_and_JT(p["functional"], psiT, p["tgt"])
+        eps_new = eng.iteration(p["eps"], chiT, p["S"], p["lam"])[0]
+    eps_o = oracle_c.iteration(p["H0"], p["Hc"], p["tlist"], p["eps"], p["S"], p["lam"], p["psi0"], chiT, mode=1, nthreads=8)[0]
+    assert _rel(eps_new, eps_o) < 1e-10
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, options={"PULSE_FAULT": 1}) as eng:
+        eng.set_initial_states(p["psi0"])
+        eng.forward(p["eps"])
+        with pytest.raises(kr.KrotovHipError) as ei:
+            eng.iteration(p["eps"], chiT, p["S"], p["lam"])
+        assert ei.value.code == capi.KR_ERR_INTERNAL and "gathered other totals than the reference workgroup" in str(ei.value), str(ei.value)
