@@ -497,7 +497,7 @@ def main():
         # command; bench.py itself does not run under rocprofv3).  Only quoted for the configuration it was taken on.
         traffic, traffic_src = None, None
         try:
-            for name in ("r04_traffic_all.json", "r03_traffic_all.json", "r02_traffic_all.json", "r01_traffic.json"):
+            for name in ("r05_traffic_all.json", "r04_traffic_all.json", "r03_traffic_all.json", "r02_traffic_all.json", "r01_traffic.json"):
                 path = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(path):
                     continue
