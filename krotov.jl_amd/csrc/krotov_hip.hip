@@ -1105,7 +1105,7 @@ static hipError_t alloc_mailbox(kr_handle *h, unsigned long long **p, size_t wor
 
 // one run of kr_mail_selftest on a region; st[0] != 0 afterwards: the region failed (st[2]: workgroup | round << 16 | replica << 24)
 static int mailbox_selftest(kr_handle *h, unsigned long long *base, int P, int replicas, size_t rstride, int sgran, int width, int fault, unsigned (&st)[KR_STATUS_WORDS]) {
-    hipLaunchKernelGGL(kr_mail_selftest, dim3(P), dim3(64), 0, h->own_stream, base, P, replicas, rstride, sgran, width, (unsigned long long)2000000ull /* 20 ms */, fault, h->status_d);
+    hipLaunchKernelGGL(kr_mail_selftest, dim3(P), dim3(64), 0, h->own_stream, base, P, replicas, rstride, sgran, width, (unsigned long long)10000000ull /* 100 ms */, fault, h->status_d);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(st, h->status_d, sizeof st, hipMemcpyDeviceToHost, h->own_stream));
     HIPCHK(h, hipStreamSynchronize(h->own_stream));
@@ -1422,7 +1422,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
             if (rc != KR_OK) return bail(rc);
             if (st[0] != 0) {
                 quarantine_block(h->gmail_d); h->gmail_d = nullptr;
-                fail(h, KR_ERR_INTERNAL, "kr_create: the freshly allocated all-gather mailbox failed its self-test (workgroup %u did not see every published word within 20 ms): "
+                fail(h, KR_ERR_INTERNAL, "kr_create: the freshly allocated all-gather mailbox failed its self-test (workgroup %u did not see every published word within 100 ms): "
                      "device memory of this process loses stores or hides them from some XCDs; the block is set aside -- call kr_create again", st[2] & 0xffffu);
                 return bail(KR_ERR_INTERNAL);
             }
@@ -1548,7 +1548,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         h->quarantined++;
         if (attempt == 2) {
             fail(h, KR_ERR_INTERNAL, "kr_create: three freshly allocated mailboxes failed their self-test (workgroup %u, round %u, replica %u of the last one did not see every "
-                 "published word within 20 ms): device memory of this process loses stores or hides them from some XCDs; see INTEGRATION.md, \"freed uncached blocks\"",
+                 "published word within 100 ms): device memory of this process loses stores or hides them from some XCDs; see INTEGRATION.md, \"freed uncached blocks\"",
                  st[2] & 0xffffu, (st[2] >> 16) & 0xffu, st[2] >> 24);
             return bail(KR_ERR_INTERNAL);
         }
@@ -1575,7 +1575,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
             if (rc != KR_OK) return bail(rc);
             if (st[0] != 0) {
                 quarantine_block(h->xmail_d); h->xmail_d = nullptr;
-                fail(h, KR_ERR_INTERNAL, "kr_create: the mailbox between GPUs failed its self-test (workgroup %u did not see every published word within 20 ms); the block is set aside -- call kr_create again", st[2] & 0xffffu);
+                fail(h, KR_ERR_INTERNAL, "kr_create: the mailbox between GPUs failed its self-test (workgroup %u did not see every published word within 100 ms); the block is set aside -- call kr_create again", st[2] & 0xffffu);
                 return bail(KR_ERR_INTERNAL);
             }
             CHK(hipMemsetAsync(h->xmail_d, 0, xwords * sizeof(unsigned long long), h->own_stream)); CHK(hipStreamSynchronize(h->own_stream));
