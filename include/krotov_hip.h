@@ -90,7 +90,9 @@ enum kr_exchange {
 enum kr_prop_method {
     KR_PROP_AUTO = 0,    /* Taylor in the update sweep, batched exact propagators in the known-pulse sweeps    */
     KR_PROP_TAYLOR = 1,
-    KR_PROP_CHEBY = 2,   /* Chebyshev expansion; Hermitian generators only                                     */
+    KR_PROP_CHEBY = 2,   /* Chebyshev expansion; Hermitian generators only.  With a persistent plan: the same
+                            truncation in powers of the generator, per-step spectral bound (persistent kernels);
+                            else / option CHEBY_RECURRENCE=1: the three-term recurrence (generic kernels)         */
     KR_PROP_NEWTON = 3   /* Newton interpolation at Leja points on the spectral bounding box                   */
 };
 

@@ -145,6 +145,7 @@ struct kr_handle {
     double *du_host = nullptr;   // pinned, callback exchange
     int exchange = KR_EXCHANGE_AUTO;   // resolved at kr_create
     int method = KR_PROP_AUTO;         // kr_prop_method; Chebyshev / Newton run on the generic kernels
+    bool cheby_served = false;         // prop_method = CHEBY carried by the persistent kernels (make_plan); `method` is AUTO then
     double *ptab_d = nullptr, *erange_d = nullptr;
     double *poly_d = nullptr;          // non-linear controls: [L][poly_deg + 1] coefficients of f_l (generic kernels), or nullptr
     // ... on the persistent kernels (round 5): the known-pulse sweeps of every family are launched with the amplitudes f_l(eps) in the
@@ -268,7 +269,7 @@ static void pack_generator_rowsplit(int N, int NP, int NR, const zc *M, bool adj
 // ("NAME=value;NAME=value", names without the KROTOV_HIP_ prefix; kept in the handle); the environment variable KROTOV_HIP_<NAME>
 // is the fallback for the lab.  kr_create rejects a name that is not in this list (a typo would otherwise be silently ignored).
 static const char *const kr_option_names[] = {
-    "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
+    "APPLY_KT", "CALIBRATE", "CALIBRATE_CACHE", "CHEBY_RECURRENCE", "ECON", "ECON_PAIR", "EXPM_MFMA", "EXPM_PS", "GATHER_DELAY", "GATHER_DELAY_LOCAL", "GENERIC",
     "GENERIC_FUSED", "HERM", "KT", "MAIL_MEM", "MAX_WG", "MFMA_APPLY", "MFMA_APPLY_KT", "MFMA_SWEEP", "MAIL_SELFTEST", "MAIL_FAULT", "PACK_CHECK", "PACK_FAULT", "POLL_DELAY", "PRECOMP", "PULSE_CHECK", "PULSE_FAULT", "RCCL_CACHE", "ROWSPLIT",
     "RS512", "RS_BATCH", "RS_FAULT", "RS_LMAX1", "RS_TURNS", "RS_PAIR", "RS_POLL_DELAY", "RS_R1", "RS_SETS", "SETS", "SHARD_SKEW_MS", "STAMPS", "TBLOCK", "TBLOCK_MIN_NT", "TBLOCK_TREE", "UC_POOL", "XCD_GROUP", "XCD_LOCAL", "XLOC_HERM", "XPOLL_DELAY", "ZERO_KERNEL", "ZERO_SYNC"};
 static bool parse_options(const char *text, std::vector<std::pair<std::string, int>> &out, std::string &bad) {
@@ -907,7 +908,13 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
     const bool nonlinear = c.control_poly_degree > 0 && h->poly_deg > 0;
     if (nonlinear && (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON))
         return fail(h, KR_ERR_UNSUPPORTED, "non-linear controls with prop_method = CHEBY / NEWTON are not supported (use TAYLOR)");
-    const bool poly = (h->method == KR_PROP_CHEBY || h->method == KR_PROP_NEWTON);   // these live in the generic kernels
+    // Chebyshev, Hermitian generators (round 5): the persistent update kernels already evaluate the Chebyshev truncation of the step
+    // (kr_device.h, "economized step polynomial": the expansion of exp(-i theta x) cut at the same bound, rewritten in powers of the
+    // generator, spectral bound per step), and the known-pulse sweeps apply batched propagators built to the same tolerance -- so a
+    // CHEBY request is served there whenever the problem has a persistent plan.  The three-term recurrence on ONE spectral range
+    // (5 x the guess amplitude, optimize.jl:238-244) stays on the generic kernels: KROTOV_HIP_CHEBY_RECURRENCE=1, or no persistent plan.
+    const bool cheb_try = h->method == KR_PROP_CHEBY && genv != 1 && opt_int(h, "CHEBY_RECURRENCE", 0) == 0;
+    bool poly = (h->method == KR_PROP_CHEBY && !cheb_try) || h->method == KR_PROP_NEWTON;   // these live in the generic kernels
     // (non-linear controls, round 5: the known-pulse sweeps of every persistent family take the amplitudes f_l(eps) in the place of the
     //  pulses; the update sweep has persistent instantiations for N <= 64 and degree <= 3 -- beyond that the stepped generic update)
     int rc = (genv == 1 || poly) ? KR_ERR_UNSUPPORTED : make_plan_fast(h, tg, wg_gen, c.max_workgroups);
@@ -953,6 +960,10 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
         }
     }
     if (!h->fast_ok) h->poly_fast = false;
+    if (cheb_try) {
+        if (h->fast_ok) { h->method = KR_PROP_AUTO; h->cheby_served = true; }
+        else poly = true;
+    }
     if (!h->fast_ok && genv == 0 && !poly) return rc;
     // exchange
     int ex = c.exchange;
@@ -1344,7 +1355,7 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     }
     h->dt_host.assign(NT, 0.0);
     for (int n = 0; n < NT; ++n) h->dt_host[n] = cfg->tlist[n + 1] - cfg->tlist[n];
-    if (h->method == KR_PROP_CHEBY) {   // Chebyshev needs real spectra: every operator exactly Hermitian
+    if (cfg->prop_method == KR_PROP_CHEBY) {   // Chebyshev needs real spectra: every operator exactly Hermitian
         for (int g = 0; g < G; ++g)
             for (int m = 0; m <= L; ++m) {
                 const zc *M = (m == 0) ? H0 + (size_t)g * nn : Hc + ((size_t)g * L + (m - 1)) * nn;
@@ -1587,22 +1598,34 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
     rc = calibrate_exchange(h);
     if (rc != KR_OK) return bail(rc);
     {   // kr_plan_description(): which kernels carry this problem, and why if not the persistent ones
-        char buf[1400];
+        char buf[2100];
         const char *upd = h->gen_update ? "generic per-step kernels (kr_gen_partial/reduce/form/apply)"
                         : h->rowsplit ? (h->rs_pair ? "kr_rowsplit_pair_sweep (two interleaved trajectories per group)"
                                          : h->rs_turns > 0 ? "kr_rowsplit_turns_update (the groups of workgroups carry several trajectories in turn)" : "kr_rowsplit_sweep")
                         : h->mfma_sweep ? "kr_mf_update (matrix cores)"
                         : h->NP > 64 ? "kr_stream_update" : "kr_sweep_update";
         const char *known = h->gen_known ? "kr_gen_known" : h->rowsplit ? (h->rs_batch > 0 ? "kr_rowsplit_sweep in batches of launches" : "kr_rowsplit_sweep") : h->precomp ? "kr_expm + kr_sweep_apply" : "kr_sweep_known";
+        char known_tb[160];
+        if (h->tb_S > 0) {
+            snprintf(known_tb, sizeof known_tb, "time blocks on the matrix cores (kr_expm_mfma64 + %s + %s over %d block propagators + kr_tb_apply, block length %d)",
+                     h->tb_tree ? "kr_tb_pair tree" : "kr_tb_products", h->mfma_sweep ? "kr_mf_apply_sweep" : "kr_sweep_apply", h->tb_NB, h->tb_S);
+            known = known_tb;
+        }
         static const char *const exn[] = {"auto", "mailbox", "rccl", "callback"};
         snprintf(buf, sizeof buf, "N=%d (padded %d) NT=%d K=%d (padded %d) L=%d G=%d rank %d/%d on device %d: update sweep = %s, %d workgroups x %d "
                  "trajectories, sets per workgroup %d, one-XCD placement %d, R=%d, HERM=%d, economized=%d, poll_delay=%d; known-pulse sweeps = %s; exchange = %s; spin bound %.0f ms; "
-                 "integrity checks: operator-copy checksums %s, group coherence words %s, per-step totals of all workgroups compared %s, mailbox self-test %s%s%s%s",
+                 "integrity checks: operator-copy checksums %s, group coherence words %s, per-step totals of all workgroups compared %s, mailbox self-test %s%s%s%s%s",
                  h->cfg.N, h->NP, h->cfg.NT, h->cfg.K, h->Kp, h->cfg.L, h->G, h->cfg.rank, h->cfg.world, h->device, upd, h->P, h->KTILE, h->rs_turns > 0 ? h->rs_turns : h->sets,
                  h->wg_stride > 1 ? 1 : 0, h->rowsplit ? h->R : 1, h->herm ? 1 : 0, (h->econ || h->econ_gen) ? 1 : 0, h->poll_delay, known, exn[h->exchange & 3], (double)h->spin_ticks / 1e5,
                  h->pack_words_d ? "on" : "off", (h->rowsplit && h->R > 1) ? "on" : "n/a", (h->pulse_check && h->dulog_d) ? "on" : "n/a",
                  (h->gen_update || opt_int(h, "MAIL_SELFTEST", 1) == 0) ? "off" : (h->quarantined ? "passed after setting blocks aside" : "passed"),
                  opt_int(h, "UC_POOL", 1) == 0 ? "; WARNING: UC_POOL=0 (diagnostics only): uncached mailboxes are freed again, and blocks that reuse their address range lose stores on this platform" : "",
+                 !h->cheby_served ? ""
+                 : h->gen_update ? "; prop_method = CHEBY is served by this plan's own step polynomials at the same tolerance (stepped update sweep: economized Taylor); "
+                                   "KROTOV_HIP_CHEBY_RECURRENCE=1 selects the three-term recurrence on the generic kernels"
+                 : "; prop_method = CHEBY is served by the persistent kernels: the update sweep evaluates the Chebyshev truncation of the step in powers of the "
+                   "generator (spectral bound per step; a step whose updated pulse leaves it takes the Taylor polynomial), the known-pulse sweeps take "
+                   "their usual plan at the same tolerance; KROTOV_HIP_CHEBY_RECURRENCE=1 selects the three-term recurrence on the generic kernels",
                  h->plan_note.empty() ? "" : "; note: ", h->plan_note.c_str());
         h->plan_text = buf;
     }

@@ -219,6 +219,19 @@ def test_propagator_methods_vs_oracle(oracle_c, method):
     nonuni["tlist"] = np.cumsum(np.r_[0.0, rng.uniform(0.05, 0.2, 12)])   # one table row per distinct dt
     cases.append(nonuni)
     for p in cases:
+        info = _check(oracle_c, p, prop_method=method, options={"CHEBY_RECURRENCE": 1})
+        assert info["generic_known"] == 1 and info["generic_update"] == 1
+    if method == capi.KR_PROP_CHEBY:
+        # round 5: without the option a Chebyshev request with a persistent plan stays on the persistent kernels (the update sweep's
+        # economized polynomial IS the Chebyshev truncation of the step, in powers of the generator) -- same tolerances
+        for p in cases:
+            K = p["psi0"].shape[0]
+            info = _check(oracle_c, p, prop_method=method)
+            assert info["generic_known"] == 0 and info["generic_update"] == 0
+            with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], K, prop_method=method) as eng:
+                assert "prop_method = CHEBY is served by the persistent kernels" in eng.plan(), eng.plan()
+        # ... and without a persistent plan (L > 4 here) the recurrence on the generic kernels, as before
+        p = wl.dense_problem(9, 8, 3, 5, 608, 0.1, 5.0)
         info = _check(oracle_c, p, prop_method=method)
         assert info["generic_known"] == 1 and info["generic_update"] == 1
     if method == capi.KR_PROP_NEWTON:     # non-Hermitian generator (a Liouvillian): Newton only
@@ -236,7 +249,7 @@ def test_polynomial_propagator_reports_a_control_that_leaves_its_range(oracle_c)
     """Chebyshev / Newton are initialised for 5 x the guess amplitude; an update beyond that must be reported, not
     propagated with a polynomial that no longer covers the spectrum."""
     p = wl.dense_problem(8, 10, 3, 1, 610, 0.1, 1e-4)      # tiny lambda_a: a huge update
-    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 3, prop_method=capi.KR_PROP_CHEBY) as eng:
+    with kr.HipEngine(p["H0"], p["Hc"], p["tlist"], 3, prop_method=capi.KR_PROP_CHEBY, options={"CHEBY_RECURRENCE": 1}) as eng:
         eng.set_initial_states(p["psi0"])
         psiT = eng.forward(p["eps"])
         _, _, chiT = wl.chi_and_JT("ss", psiT, p["tgt"])

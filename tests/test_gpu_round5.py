@@ -180,6 +180,7 @@ def test_known_pulse_sweeps_in_blocks_of_time_vs_oracle(case, oracle_c):
     for name, o in (("blocks", dict(opts)), ("sequential", dict(opts, TBLOCK=0))):
         with kr.HipEngine(H0, Hc, p["tlist"], K, options=o, **kw) as eng:
             assert eng.info()["precomputed_propagators"] == 1, eng.plan()
+            assert ("time blocks on the matrix cores" in eng.plan()) == (name == "blocks"), eng.plan()
             eng.set_initial_states(p["psi0"])
             psiT = eng.forward(p["eps"])
             fw = np.stack([np.stack([eng.read_storage("fw", k, n) for k in (0, K // 2, K - 1)]) for n in range(NT + 1)])
