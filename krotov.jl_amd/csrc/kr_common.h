@@ -91,6 +91,8 @@ struct KrSweepArgs {
     // sweep what depends on the GUESS only -- amp_g[l][n] = f_l(eps_guess), fprime_g[l][n] = f_l'(eps_guess), both [L][NT] -- and the
     // coefficients poly[l][0..3] for the one evaluation per step that cannot be made in advance, f_l(eps_new).  (Known-pulse sweeps need
     // nothing: they are launched with the amplitudes f_l(eps) in the place of the pulses.)  All three nullptr: linear controls.
+    // The row-split update kernels (kr_device_rowsplit.h; run-time branch, no instantiation of their own) take the roles the other way
+    // round: `eps` = f_l(eps_guess) -- what their resident H(eps) blocks are built from -- and `amp_g` = the guess PULSES.
     const double *amp_g, *fprime_g, *poly;
     // Known-pulse sweeps in blocks of time (round 5; kr_device_tblock.h, NP = 64): steps [b S, (b + 1) S) form block b; tb_bound holds
     // the state at every block boundary ([NB + 1][Kp][N], written by the sequential apply sweep over the block propagators),

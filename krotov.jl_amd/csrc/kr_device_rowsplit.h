@@ -403,6 +403,11 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
         const int n = (a.dir > 0) ? step : (NT - 1 - step);
         const double dtn = a.dt[n];
         const double sdt = (a.dir > 0) ? dtn : -dtn;
+        // e / eg / de / ecur are the AMPLITUDES the control blocks are combined with.  Linear controls: the pulses themselves.  Non-linear
+        // controls (UPDATE with KrSweepArgs::poly, round 5; kr_sweep_update<.., POLY> in kr_device.h): the host hands over a.eps = f_l(eps_guess)
+        // as it does for the known-pulse sweeps; the guess PULSES the update is added to ride in a.amp_g (sic: the row-split kernels' use of
+        // that field) and f_l'(eps_guess) in a.fprime_g, both fetched behind the exchange -- nothing more is live across it, the linear path
+        // is the code it was.
         double e[LMAX], eg[LMAX], de[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) { eg[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0; e[l] = eg[l]; de[l] = 0.0; }
@@ -439,11 +444,20 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
             for (int l = 0; l < LMAX; ++l) {
                 if (l < L) {
                     const double alpha = a.alpha[(size_t)l * NT + n];
-                    e[l] = __dadd_rn(eg[l], __dmul_rn(alpha, du[l]));
+                    double dul = du[l], pn;
+                    if (a.poly) {   // mu_l = f_l'(eps_guess) H_l (optimize.jl:337,345); the amplitude of the updated pulse: f_l(pg + d) as the cubic's Taylor form at pg
+                        const double pg = a.amp_g[(size_t)l * NT + n], fp = a.fprime_g[(size_t)l * NT + n], c2 = a.poly[4 * l + 2], c3 = a.poly[4 * l + 3];
+                        dul = __dmul_rn(fp, du[l]);
+                        pn = __dadd_rn(pg, __dmul_rn(alpha, dul));
+                        e[l] = eg[l] + kr_poly3_delta(pn - pg, fp, fma(3.0 * c3, pg, c2), c3);
+                    } else {
+                        pn = __dadd_rn(eg[l], __dmul_rn(alpha, dul));
+                        e[l] = pn;
+                    }
                     de[l] = e[l] - eg[l];
-                    const double ad = fabs(du[l]);
+                    const double ad = fabs(dul);
                     gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dtn));
-                    if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = e[l];
+                    if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = pn;
                 }
             }
             // H(eps_new) = H(eps_g) + sum_l d eps_l H_l  (second streamed pass over the control blocks only)
@@ -637,7 +651,7 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
     };
     for (int n = 0; n < NT; ++n) {
         const double dtn = a.dt[n];
-        double e[LMAX], eg[LMAX], de[LMAX], dinc[LMAX], zero[LMAX];
+        double e[LMAX], eg[LMAX], de[LMAX], dinc[LMAX], zero[LMAX];   // (amplitudes; non-linear controls as in kr_rowsplit_sweep)
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) { eg[l] = (l < L) ? a.eps[(size_t)l * NT + n] : 0.0; e[l] = eg[l]; de[l] = 0.0; dinc[l] = eg[l] - ecur[l]; zero[l] = 0.0; }
         const double ec = econ_rows ? econ_rows[(size_t)n * KR_ECON_W] : 0.0;
@@ -679,11 +693,20 @@ __global__ __launch_bounds__((KrGeomR<NP, NR, LMAX>::THREADS), (KrGeomR<NP, NR, 
         for (int l = 0; l < LMAX; ++l) {
             if (l < L) {
                 const double alpha = a.alpha[(size_t)l * NT + n];
-                e[l] = __dadd_rn(eg[l], __dmul_rn(alpha, du[l]));
+                double dul = du[l], pn;
+                if (a.poly) {
+                    const double pg = a.amp_g[(size_t)l * NT + n], fp = a.fprime_g[(size_t)l * NT + n], c2 = a.poly[4 * l + 2], c3 = a.poly[4 * l + 3];
+                    dul = __dmul_rn(fp, du[l]);
+                    pn = __dadd_rn(pg, __dmul_rn(alpha, dul));
+                    e[l] = eg[l] + kr_poly3_delta(pn - pg, fp, fma(3.0 * c3, pg, c2), c3);
+                } else {
+                    pn = __dadd_rn(eg[l], __dmul_rn(alpha, dul));
+                    e[l] = pn;
+                }
                 de[l] = e[l] - eg[l];
-                const double ad = fabs(du[l]);
+                const double ad = fabs(dul);
                 gint[l] = __dadd_rn(gint[l], __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dtn));
-                if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = e[l];
+                if (wg == 0 && tid == 0) a.eps_new[(size_t)l * NT + n] = pn;
             }
         }
         {   // H(eps_new) = H(eps_g) + sum_l d eps_l H_l
