@@ -130,3 +130,71 @@ def test_the_shim_replays_the_per_step_propagation_callbacks():
     assert "replay_prop_callbacks!(eng, wrk, :fw)" in init
     it = SHIM[SHIM.index("function iteration!"):SHIM.index("# ---- 3.")]
     assert it.index("replay_prop_callbacks!(eng, wrk, :bw)") < it.index("replay_prop_callbacks!(eng, wrk, :fw)")
+
+
+def _julia_code_only(src):
+    """The source with comments, string literals and character literals blanked out (what a block scanner may look at)."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith("#=", i):
+            i = src.index("=#", i) + 2
+        elif c == "#":
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith('"""', i):
+            i = src.index('"""', i + 3) + 3
+            out.append('""')
+        elif c == '"':
+            j = i + 1
+            while src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            i = j + 1
+            out.append('""')
+        elif c == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and src[i + 3] == "'")):
+            i += 3 if src[i + 2] == "'" else 4
+            out.append("' '")
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def _scan_blocks(code):
+    """-> list of problems: every block opener (function / if / for / while / let / begin / struct / module / try / do / quote / macro;
+    `for` / `if` inside brackets are comprehensions) must meet its `end`, `end` inside brackets is an index, brackets must close."""
+    openers = {"function", "if", "for", "while", "let", "begin", "struct", "module", "baremodule", "try", "do", "quote", "macro"}
+    problems, stack, brackets, prev = [], [], [], None
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for m in re.finditer(r"[A-Za-z_][A-Za-z_0-9!]*|[\[\]\(\)\{\}]|:(?=[A-Za-z_])|\.", code):
+        t, line = m.group(0), code.count("\n", 0, m.start()) + 1
+        if t in "([{":
+            brackets.append((t, line))
+        elif t in ")]}":
+            if brackets and brackets[-1][0] == pairs[t]:
+                brackets.pop()
+            else:
+                problems.append("line %d: unmatched %s" % (line, t))
+        elif t in openers and prev not in (":", "."):
+            if not (brackets and t in ("for", "if")):
+                stack.append((t, line))
+        elif t == "end" and prev not in (":", ".") and not brackets:
+            if stack:
+                stack.pop()
+            else:
+                problems.append("line %d: `end` without an open block" % line)
+        prev = t
+    problems += ["`%s` of line %d never closed" % b for b in stack] + ["`%s` of line %d never closed" % b for b in brackets]
+    return problems
+
+
+def test_the_shim_s_blocks_and_brackets_balance():
+    """No Julia parser here, but the commonest way to break a file nobody can run is a lost `end` or bracket."""
+    code = _julia_code_only(SHIM)
+    assert not re.search(r"\b(abstract|primitive)\s+type\b", code)     # (would need `type` as an opener)
+    assert _scan_blocks(code) == []
+    # the scanner itself: indices, comprehensions, symbols and strings are not blocks; a lost `end` and a stray bracket are found
+    ok = 'function f(x)\n  y = [i for i in x if i > 0]\n  if x[end] > 0 # end\n    return :end, "end"\n  end\nend\n'
+    assert _scan_blocks(_julia_code_only(ok)) == []
+    assert _scan_blocks(_julia_code_only(ok.replace("  end\nend", "end"))) != []
+    assert _scan_blocks(_julia_code_only(ok.replace("x[end]", "x[end"))) != []
