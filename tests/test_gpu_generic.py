@@ -314,3 +314,56 @@ def test_nonlinear_polynomial_controls(shape, deg, persistent):
         psi = psi @ o.step_propagator(H0, Hc, amp(eps_o[:, n]), tl[n + 1] - tl[n]).T
     assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < 1e-9 and np.max(np.abs(psiT1 - psi)) < 1e-10
     assert np.max(np.abs(eps_new - eps)) > 1e-4
+
+
+@pytest.mark.parametrize("shape", [(20, 14, 30, 2), (64, 10, 300, 2), (100, 5, 9, 1)], ids=["np32", "np64_two_generators_300", "rowsplit_np128"])
+def test_nonlinear_controls_with_per_trajectory_generators(shape):
+    """Non-linear controls together with an ensemble of distinct generators (both at once, /root/reference/src/
+    optimize.jl:268-272,337,343-347 -- mu_kl = f_l'(eps_l) H_l^(g(k)) differs per trajectory): the persistent update kernels, against the
+    serial restatement built on the oracle's exact step propagator, generator by generator."""
+    import krotov_oracle as o
+    N, NT, K, L = shape
+    p = wl.dense_problem(N, NT, K, L, 640 + N, 0.05, 0.5)
+    tl, eps, S, lam, psi0, tgt = (p[k] for k in ("tlist", "eps", "S", "lam", "psi0", "tgt"))
+    rng = np.random.default_rng(641)
+    H0 = np.stack([p["H0"], 0.7 * p["H0"] + 0.1 * np.diag(rng.normal(size=N))])
+    Hc = np.stack([p["Hc"], 1.3 * p["Hc"]])
+    tg = rng.integers(0, 2, K).astype(np.int32)
+    tg[:2] = [0, 1]
+    poly = np.array([[0.0, 1.0, 0.5, 0.3], [0.05, 0.9, 0.0, 1.0]][:L])
+    f = lambda l, x: sum(poly[l, q] * x ** q for q in range(4))
+    fp = lambda l, x: sum(q * poly[l, q] * x ** (q - 1) for q in range(1, 4))
+    amp = lambda e: np.array([f(l, e[l]) for l in range(L)])
+    with kr.HipEngine(H0, Hc, tl, K, control_poly=poly, traj_generator=tg) as eng:
+        info = eng.info()
+        assert info["generic_update"] == 0 and info["generic_known"] == 0, eng.plan()
+        eng.set_initial_states(psi0)
+        psiT = eng.forward(eps)
+        Us = [[o.step_propagator(H0[g], Hc[g], amp(eps[:, n]), tl[n + 1] - tl[n]) for n in range(NT)] for g in range(2)]
+        psi = psi0.copy()
+        for n in range(NT):
+            for g in range(2):
+                psi[tg == g] = psi[tg == g] @ Us[g][n].T
+        assert np.max(np.abs(psiT - psi)) < 1e-11
+        _, _, chiT = wl.chi_and_JT("ss", psi, tgt)
+        eps_new, ga, psiT1 = eng.iteration(eps, chiT, S, lam)
+    X = np.empty((NT + 1, K, N), complex)
+    X[NT] = chiT
+    for n in range(NT - 1, -1, -1):
+        for g in range(2):
+            X[n][tg == g] = X[n + 1][tg == g] @ Us[g][n].conj()
+    psi, eps_o, ga_o = psi0.copy(), eps.copy(), np.zeros(L)
+    for n in range(NT):
+        for l in range(L):
+            du = 0.0
+            for g in range(2):
+                m = tg == g
+                du += np.sum(np.einsum("ki,ki->k", X[n][m].conj(), psi[m] @ Hc[g][l].T).imag)
+            du *= fp(l, eps[l, n])
+            eps_o[l, n] = eps[l, n] + S[l, n] / lam[l] * du
+            ga_o[l] += S[l, n] / lam[l] * du * du * (tl[n + 1] - tl[n])
+        for g in range(2):
+            m = tg == g
+            psi[m] = psi[m] @ o.step_propagator(H0[g], Hc[g], amp(eps_o[:, n]), tl[n + 1] - tl[n]).T
+    assert _rel(eps_new, eps_o) < TOL_PULSE and _rel(ga, ga_o) < 1e-9 and np.max(np.abs(psiT1 - psi)) < 1e-10
+    assert np.max(np.abs(eps_new - eps)) > 1e-4
