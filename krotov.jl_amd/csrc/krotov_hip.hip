@@ -162,6 +162,7 @@ struct kr_handle {
     kr_allreduce_fn cb = nullptr;
     void *cb_ctx = nullptr;
     ncclComm_t rccl_comm = nullptr;
+    bool rccl_bad = false;             // a collective on rccl_comm failed: the communicator does not go back into the cache
     // timing: per kind (0 forward, 1 backward, 2 update) a pool of event pairs, one per launch since
     // the last reset; durations are read back (after a stream sync) by kr_get_timings
     bool timing = false;
@@ -2027,7 +2028,7 @@ static int launch_update_stepped(kr_handle *h, const double *eps_guess_dev, doub
         HIPCHK(h, kr_launch_generic(2, h->KTG, 1, 0, h->stream, &g));
         if (use_rccl) {
             const ncclResult_t r = kr_rccl()->AllReduce(h->du_local_d, h->du_total_d, (size_t)L, ncclDouble, ncclSum, h->rccl_comm, h->stream);
-            if (r != ncclSuccess) return fail(h, KR_ERR_HIP, "ncclAllReduce failed at step %d: %s", n, kr_rccl()->GetErrorString(r));
+            if (r != ncclSuccess) { h->rccl_bad = true; return fail(h, KR_ERR_HIP, "ncclAllReduce failed at step %d: %s", n, kr_rccl()->GetErrorString(r)); }
         } else if (use_cb) {
             HIPCHK(h, hipMemcpyAsync(h->du_host, h->du_local_d, (size_t)L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2608,7 +2609,7 @@ static int one_iteration_functional_dev(kr_handle *h, int functional, const void
         HIPCHK(h, hipGetLastError());
         if (tau_rccl) {   // (sum order = RCCL's: identical on every rank, as the update sweep's all-reduce is)
             const ncclResult_t r = kr_rccl()->AllReduce(h->tausum_d, h->tausum_d, 2, ncclDouble, ncclSum, h->rccl_comm, h->stream);
-            if (r != ncclSuccess) return fail(h, KR_ERR_HIP, "ncclAllReduce of the tau sum failed: %s", kr_rccl()->GetErrorString(r));
+            if (r != ncclSuccess) { h->rccl_bad = true; return fail(h, KR_ERR_HIP, "ncclAllReduce of the tau sum failed: %s", kr_rccl()->GetErrorString(r)); }
         } else if (tau_cb) {
             double buf[2];
             HIPCHK(h, hipMemcpyAsync(buf, h->tausum_d, sizeof buf, hipMemcpyDeviceToHost, h->stream));
@@ -2724,14 +2725,15 @@ static void rccl_cache_add(const std::vector<int> &key, ncclComm_t c) {
     std::lock_guard<std::mutex> g(g_comm_mtx);
     g_comms.push_back({key, c, true});
 }
-static bool rccl_cache_unuse(ncclComm_t c) {
+// `bad`: a collective on this communicator failed -- it is never handed out again (and, like every cached one, never destroyed)
+static bool rccl_cache_unuse(ncclComm_t c, const bool bad = false) {
     std::lock_guard<std::mutex> g(g_comm_mtx);
-    for (auto &e : g_comms) if (e.comm == c) { e.in_use = false; return true; }
+    for (auto &e : g_comms) if (e.comm == c) { e.in_use = bad; return true; }
     return false;
 }
 static void rccl_release(kr_handle *h) {
     if (!h->rccl_comm) return;
-    if (!rccl_cache_unuse(h->rccl_comm) && kr_rccl()) (void)kr_rccl()->CommDestroy(h->rccl_comm);   // (not cached: KROTOV_HIP_RCCL_CACHE=0)
+    if (!rccl_cache_unuse(h->rccl_comm, h->rccl_bad) && kr_rccl()) (void)kr_rccl()->CommDestroy(h->rccl_comm);   // (not cached: KROTOV_HIP_RCCL_CACHE=0)
     h->rccl_comm = nullptr;
 }
 
@@ -2883,6 +2885,9 @@ static void group_quiesce(kr_handle *g) {
 }
 static int group_destroy(kr_handle *g) {
     group_quiesce(g);   // ALL streams first: one_destroy waits for its own shard's stream only
+    bool bad = false;   // a failed collective on one shard's communicator retires the whole set (rccl_release)
+    for (kr_handle *s : g->subs) if (s && s->rccl_bad) bad = true;
+    for (kr_handle *s : g->subs) if (s && bad) s->rccl_bad = true;
     for (kr_handle *s : g->subs) if (s) (void)one_destroy(s);
     delete g;
     return KR_OK;
