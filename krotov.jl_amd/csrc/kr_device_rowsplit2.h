@@ -231,8 +231,11 @@ __device__ __forceinline__ void kr_pair_row_dot(const double (&Er)[JS], const do
 // exchange, then the rounds of every set; between its turns a set keeps psi(t_n) (the all-gathered vectors) in a per-workgroup
 // global scratch and the phase-A products of its rows in LDS.  N = 256 with 65..256 trajectories: ~S x the C5 step instead of
 // the streamed-generator kernels (8 x).  MULTI = false is the kernel of C5, unchanged.
+// POLY (round 5; update sweep only): a non-linear control -- `eps` carries f(eps_guess), `amp_g` the guess pulses, `fprime_g` f'(eps_guess),
+// `poly` the cubic's coefficients, as in kr_rowsplit_sweep (kr_device_rowsplit.h).  An instantiation of its own: as a run-time branch the
+// same lines cost the linear kernel of C5 8 B more scratch and 0.8 % (36.71 -> 37.01 ms per update sweep).
 #define KR_PAIR_MAX_SETS 4
-template <int NP, int NR, bool UPDATE, bool MULTI = false>
+template <int NP, int NR, bool UPDATE, bool MULTI = false, bool POLY = false>
 __global__ __launch_bounds__(512, 2) void kr_rowsplit_pair_sweep(const KrSweepArgs a) {
     using G = KrGeomR<NP, NR, 1>;
     constexpr int JS = G::JS, JQ = G::JQ, R = G::R, T = G::THREADS, KP = 2;
@@ -541,14 +544,23 @@ kr_next_set:
             if (!kr_exchange<2, NR, KR_RS_SCHED>(a, n, wg, owner, il, part, du, spart, stot)) return;
             KR_STAMP(tX)
             const double alpha = a.alpha[n];
-            e = __dadd_rn(eg, __dmul_rn(alpha, du[0]));
+            double dul = du[0], pn;
+            if constexpr (POLY) {   // mu = f'(eps_guess) H_1 (optimize.jl:337,345); the amplitude of the updated pulse as the cubic's Taylor form at the guess
+                const double pg = a.amp_g[n], fp = a.fprime_g[n], c2 = a.poly[2], c3 = a.poly[3];
+                dul = __dmul_rn(fp, du[0]);
+                pn = __dadd_rn(pg, __dmul_rn(alpha, dul));
+                e = eg + kr_poly3_delta(pn - pg, fp, fma(3.0 * c3, pg, c2), c3);
+            } else {
+                pn = __dadd_rn(eg, __dmul_rn(alpha, dul));
+                e = pn;
+            }
             de = e - eg;
-            const double ad = fabs(du[0]);
+            const double ad = fabs(dul);
             gint = __dadd_rn(gint, __dmul_rn(__dmul_rn(alpha, __dmul_rn(ad, ad)), dtn));
             // (no log of the gathered totals here, unlike every other persistent update kernel: this kernel sits at 256 VGPRs with scratch, and
             //  both placements of the one store -- lane 0 of wave 2 behind the exchange, or the eps_new store below redirected per workgroup
             //  -- cost C5 1.4 % of the iteration, the second one through the KNOWN-pulse instantiation of this very template, 28.55 -> 29.12 ms)
-            if (wg == 0 && tid == 0) a.eps_new[n] = e;
+            if (wg == 0 && tid == 0) a.eps_new[n] = pn;
             // H(eps_new) = H(eps_g) + d eps H_1, in registers
 #pragma unroll
             for (int jj = 0; jj < JS; ++jj) { Er[jj] = fma(de, KR_H1R(jj), Er[jj]); Ei[jj] = fma(de, KR_H1I(jj), Ei[jj]); }

@@ -8,6 +8,7 @@ hipError_t kr_launch_rs128(int lmax, int nr, int kind, int grid, hipStream_t s, 
 #define KR_CASE_P(NRv)                                                                                          \
         if (nr == NRv) {                                                                                        \
             if (kind == 2) kr_launch_kernel((kr_rowsplit_pair_sweep<128, NRv, false>), grid, 512, 0, s, *a);     \
+            else if (a->poly) kr_launch_kernel((kr_rowsplit_pair_sweep<128, NRv, true, false, true>), grid, 512, 0, s, *a); /* non-linear control */ \
             else kr_launch_kernel((kr_rowsplit_pair_sweep<128, NRv, true>), grid, 512, 0, s, *a);                \
             return hipGetLastError();                                                                           \
         }

@@ -9,12 +9,14 @@ hipError_t kr_launch_rs256(int lmax, int nr, int kind, int grid, hipStream_t s, 
         if (a->rs_sets > 1) {   // several pairs per group in turn (N = 256, 65..256 trajectories): NR = 32 only
             if (nr != 32 || a->rs_sets > KR_PAIR_MAX_SETS || a->rs_scratch == nullptr) return hipErrorInvalidValue;
             if (kind == 2) kr_launch_kernel((kr_rowsplit_pair_sweep<256, 32, false, true>), grid, 512, 0, s, *a);
+            else if (a->poly) kr_launch_kernel((kr_rowsplit_pair_sweep<256, 32, true, true, true>), grid, 512, 0, s, *a);   // non-linear control
             else kr_launch_kernel((kr_rowsplit_pair_sweep<256, 32, true, true>), grid, 512, 0, s, *a);
             return hipGetLastError();
         }
 #define KR_CASE_P(NRv)                                                                                          \
         if (nr == NRv) {                                                                                        \
             if (kind == 2) kr_launch_kernel((kr_rowsplit_pair_sweep<256, NRv, false>), grid, 512, 0, s, *a);     \
+            else if (a->poly) kr_launch_kernel((kr_rowsplit_pair_sweep<256, NRv, true, false, true>), grid, 512, 0, s, *a); \
             else kr_launch_kernel((kr_rowsplit_pair_sweep<256, NRv, true>), grid, 512, 0, s, *a);                \
             return hipGetLastError();                                                                           \
         }

@@ -152,7 +152,6 @@ struct kr_handle {
     // place of the pulses (amp_d); the N <= 64 update kernels have instantiations for degree <= 3 (poly_fast: coefficients padded to
     // four per control in poly3_d, f_l(eps_guess) in amp_d and f_l'(eps_guess) in fprime_d, rewritten in front of every sweep)
     bool poly_fast = false;
-    bool nonlinear = false;            // non-linear controls requested (make_plan; make_plan_fast keeps the row-split pair mode out of it)
     double *poly3_d = nullptr, *amp_d = nullptr, *fprime_d = nullptr;
     int poly_deg = 0;
     int ptab_stride = 0;
@@ -708,7 +707,7 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
         // N = 256, one control, shared generator, more pairs than groups of 8 workgroups: the groups carry up to 4 pairs each in turn
         // (round 3: kr_rowsplit_pair_sweep<.., MULTI>; before: the streamed-generator kernels, 8 x the time per trajectory)
         int rs_sets = 1;
-        if (NP == 256 && c.L == 1 && h->G == 1 && !h->nonlinear && opt_int(h, "RS_LMAX1", 1) != 0 && opt_int(h, "RS_PAIR", 1) != 0 &&
+        if (NP == 256 && c.L == 1 && h->G == 1 && opt_int(h, "RS_LMAX1", 1) != 0 && opt_int(h, "RS_PAIR", 1) != 0 &&
             opt_int(h, "RS_SETS", 1) != 0 && maxwg >= 8 && (long long)c.K * R > maxwg) {
             const int groups = maxwg / 8, pairs = (c.K + 1) / 2;
             const int need = (pairs + groups - 1) / groups;
@@ -742,9 +741,8 @@ static int make_plan_fast(kr_handle *h, const int32_t *tg, std::vector<int> &wg_
             // all-gather), the same workgroups in groups of 2R carry TWO trajectories with 32 rows each: both blocks resident,
             // one trajectory's all-gather behind the other's row-dot.  One control, shared generator (C5's shape); an odd K is
             // padded with one zero trajectory (it contributes nothing to any sum).  KROTOV_HIP_RS_PAIR=0 keeps the single mode.
-            // (Non-linear controls: single mode -- the pair kernel has no amplitude path, kr_device_rowsplit2.h.)
             if (NP / R == 64 && h->LMAXv == 1 && h->G == 1 && c.K >= 2 && ((long long)((c.K + 1) / 2) * (2 * R) <= maxwg || rs_sets > 1) &&
-                !h->nonlinear && opt_int(h, "RS_PAIR", 1) != 0) {
+                opt_int(h, "RS_PAIR", 1) != 0) {
                 h->rs_pair = true;
                 R *= 2;
             }
@@ -920,14 +918,13 @@ static int make_plan(kr_handle *h, const kr_config *full, std::vector<int> &wg_g
     bool poly = (h->method == KR_PROP_CHEBY && !cheb_try) || h->method == KR_PROP_NEWTON;   // these live in the generic kernels
     // (non-linear controls, round 5: the known-pulse sweeps of every persistent family take the amplitudes f_l(eps) in the place of the
     //  pulses; the update sweep has persistent instantiations for N <= 64 and degree <= 3 -- beyond that the stepped generic update)
-    h->nonlinear = nonlinear && h->poly_deg <= 3;   // (degree > 3: stepped generic update whatever the family -- the known-pulse sweeps keep the pair mode)
     int rc = (genv == 1 || poly) ? KR_ERR_UNSUPPORTED : make_plan_fast(h, tg, wg_gen, c.max_workgroups);
     h->fast_ok = (rc == KR_OK);
     if (rc != KR_OK && rc != KR_ERR_UNSUPPORTED) return rc;
     if (nonlinear && h->fast_ok) h->wg_stride = 1;   // (no one-XCD placement build of the non-linear update kernels)
-    // (row-split single / turns kernels: the same scalar change at run time, KrSweepArgs::poly; the pair mode is not planned for non-linear
-    //  controls; the streamed-generator kernels -- N > 64 without a row-split plan -- have no such path: stepped generic update)
-    h->poly_fast = nonlinear && h->fast_ok && ((h->NP <= 64 && !h->rowsplit && h->sets == 1) || (h->rowsplit && !h->rs_pair)) && h->poly_deg <= 3 &&
+    // (row-split single / turns kernels: the same scalar change at run time, KrSweepArgs::poly; pair mode: instantiations <.., POLY>;
+    //  the streamed-generator kernels -- N > 64 without a row-split plan -- have no such path: stepped generic update)
+    h->poly_fast = nonlinear && h->fast_ok && ((h->NP <= 64 && !h->rowsplit && h->sets == 1) || h->rowsplit) && h->poly_deg <= 3 &&
                    c.exchange != KR_EXCHANGE_RCCL && c.exchange != KR_EXCHANGE_CALLBACK;
     if (h->fast_ok) {
         // Co-residency: the P persistent workgroups of an update sweep spin on each other, so all of them must be resident

@@ -260,16 +260,16 @@ def test_polynomial_propagator_reports_a_control_that_leaves_its_range(oracle_c)
 
 @pytest.mark.parametrize("shape,deg,persistent", [((10, 25, 6, 2), 3, 1), ((64, 12, 256, 2), 3, 1), ((64, 8, 600, 2), 2, 1), ((33, 9, 40, 3), 3, 1),
                                                    ((10, 25, 6, 2), 5, 0), ((100, 6, 5, 1), 3, 1), ((100, 5, 200, 2), 2, 1), ((130, 5, 40, 1), 3, 1),
-                                                   ((300, 4, 12, 2), 3, 1), ((130, 4, 6, 1), 4, 0)],
-                         ids=["np16", "c3_shape_vector", "matrix_cores", "lmax4", "degree5_generic_update", "rowsplit_np128", "rowsplit_np128_r1",
-                              "rowsplit_np256_single_not_pair", "rowsplit_turns_np512", "rowsplit_degree4_generic_update"])
-def test_nonlinear_polynomial_controls(shape, deg, persistent):
+                                                   ((300, 4, 12, 2), 3, 1), ((130, 4, 6, 1), 4, 0), ((130, 4, 100, 1), 3, 1), ((100, 6, 5, 2), 3, 1), ((100, 5, 100, 1), 3, 1)],
+                         ids=["np16", "c3_shape_vector", "matrix_cores", "lmax4", "degree5_generic_update", "rowsplit_np128_few", "rowsplit_np128_r1",
+                              "rowsplit_pair_np256", "rowsplit_turns_np512", "rowsplit_degree4_generic_update", "rowsplit_pair_sets_np256", "rowsplit_single_np128", "rowsplit_pair_np128_k100"])
+def test_nonlinear_polynomial_controls(shape, deg, persistent, request):
     """Non-linear controls, static part: H(eps) = H0 + sum_l f_l(eps_l) H_l with polynomial f_l; the
     control derivative mu_l = f_l'(eps_l) H_l is evaluated at the GUESS value of the step, as _eval_mu does
     (/root/reference/src/optimize.jl:268-272,337,345).  Against a serial restatement of optimize.jl:328-370 built on the
     oracle's exact step propagator.  Round 5: degree <= 3 runs on the PERSISTENT update kernels (kr_sweep_update /
-    kr_mf_update<.., POLY> at N <= 64, the row-split single / turns kernels above with a run-time branch -- the pair mode is not
-    planned for non-linear controls; generic_update == 0), the known-pulse sweeps of every persistent family take the amplitudes
+    kr_mf_update<.., POLY> at N <= 64, the row-split single / turns kernels above with a run-time branch, the pair mode with
+    instantiations of its own; generic_update == 0), the known-pulse sweeps of every persistent family take the amplitudes
     in the place of the pulses; higher degrees keep the stepped generic update."""
     import krotov_oracle as o
     N, NT, K, L = shape
@@ -289,7 +289,8 @@ def test_nonlinear_polynomial_controls(shape, deg, persistent):
         assert info["generic_update"] == (0 if persistent else 1), eng.plan()
         assert info["generic_known"] == 0, eng.plan()
         if N > 64 and persistent:
-            assert info["rowsplit_R"] >= 1 and "kr_rowsplit_pair_sweep" not in eng.plan(), eng.plan()
+            assert info["rowsplit_R"] >= 1, eng.plan()
+            assert ("kr_rowsplit_pair_sweep" in eng.plan()) == ("pair" in request.node.callspec.id), eng.plan()
         eng.set_initial_states(psi0)
         psiT = eng.forward(eps)
         Us = [o.step_propagator(H0, Hc, amp(eps[:, n]), tl[n + 1] - tl[n]) for n in range(NT)]
