@@ -100,6 +100,10 @@ struct KrSweepArgs {
     const double2 *tb_bound;
     const int *tb_items;
     int tb_S, tb_nitems, tb_NT;
+    // N <= 32 (kr_device_prop.h: kr_tb_products_small, kr_sweep_apply<.., TB>): number of blocks, output of the block products;
+    // tb_nitems = the apply kernel's tiles per block there
+    int tb_NB;
+    double2 *tb_P;
 };
 #define KR_MAIL_XTAB_OFF ((size_t)2 * KR_MAIL_REPLICAS * KR_MAIL_RSTRIDE + 64 * 4)   // words: XCC-id table behind the mailbox + tail
 #define KR_MAIL_XTAB_WORDS 64
@@ -194,7 +198,8 @@ typedef hipError_t (*kr_launch_fn)(int variant_lmax, int variant_kt, int kind, i
                                    hipStream_t stream, const KrSweepArgs *args);
 // kind: 0 = known-pulse sweep (Taylor), 1 = update sweep, 2 = batched propagator build (grid = NT),
 //       3 = known-pulse sweep with precomputed propagators, 4 = update sweep with the delayed-poll exchange schedule
-//       (N <= 64 only), 5 / 6 = kinds 1 / 4 as kr_sweep_update<..., CAL = 1> (calibration launches)
+//       (N <= 64 only), 5 / 6 = kinds 1 / 4 as kr_sweep_update<..., CAL = 1> (calibration launches),
+//       7 / 8 = time-blocked known-pulse sweeps at N <= 32: parallel apply pass / block propagators (kr_device_prop.h)
 hipError_t kr_launch_np8(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np16(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);
 hipError_t kr_launch_np32(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a);

@@ -1342,6 +1342,10 @@ static hipError_t kr_launch_expm(int grid, hipStream_t s, const KrSweepArgs *a) 
 template <int NP>
 static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t s, const KrSweepArgs *a) {
     constexpr int CB = (NP >= 16) ? 4 : 1;
+    if (kind == 8) {   // block propagators of the time-blocked sweeps, N <= 32 (a->tb_P: the output)
+        if constexpr (NP <= 32) { kr_launch_kernel((kr_tb_products_small<NP>), grid, 256, 0, s, *a); return hipGetLastError(); }
+        else return hipErrorInvalidValue;
+    }
 #define KR_CASE(LM, KTv)                                                                          \
     if (lmax == LM && kt == KTv) {                                                                \
         if (kind == 0) kr_launch_kernel((kr_sweep_known<NP, LM, KTv>), grid, KrGeom<NP, LM, KTv>::THREADS, 0, s, *a); \
@@ -1370,6 +1374,10 @@ static hipError_t kr_launch_np(int lmax, int kt, int kind, int grid, hipStream_t
             } \
         } \
         else if (kind == 2) { const hipError_t ee_ = kr_launch_expm<NP, LM, CB>(grid, s, a); if (ee_ != hipSuccess) return ee_; } \
+        else if (kind == 7) {  /* known-pulse sweep in blocks of time, N <= 32: the parallel pass (kr_sweep_apply<.., TB>) */ \
+            if constexpr (NP <= 32) kr_launch_kernel((kr_sweep_apply<NP, KTv, 1>), grid, KrApplyGeom<NP>::THREADS, 0, s, *a); \
+            else return hipErrorInvalidValue; \
+        } \
         else kr_launch_kernel((kr_sweep_apply<NP, KTv>), grid, KrApplyGeom<NP>::THREADS, 0, s, *a);      \
         return hipGetLastError();                                                                 \
     }

@@ -120,23 +120,34 @@ __global__ __launch_bounds__((KrGeom<NP, LMAX, 1>::THREADS), (KrGeom<NP, LMAX, 1
 }
 
 // ---- known-pulse sweep with precomputed propagators: one round per step ---------------------------
-template <int NP, int KT>
+// TB = 1 (round 5, N <= 32: the known-pulse sweeps in blocks of time): the grid is blocks x tiles; workgroup (tb, tile)
+// starts from the boundary state a.tb_bound[tb] (written by the TB = 0 sweep over the block propagators), applies the steps of sweep
+// positions [tb S, tb S + len - 1) and stores every state into the slot the sequential sweep fills with it; the block's last position
+// is the next block's boundary (the last block adds the final boundary: storage's last slot == the final states, bit for bit).
+template <int NP, int KT, int TB = 0>
 __global__ __launch_bounds__((KrApplyGeom<NP>::THREADS), (KrApplyGeom<NP>::THREADS / 256)) void kr_sweep_apply(const KrSweepArgs a) {
-    const double2 *__restrict__ Upack = a.U + (size_t)(a.wg_gen ? a.wg_gen[blockIdx.x / (a.gen_div > 0 ? a.gen_div : 1)] : 0) * a.NT * NP * NP;
+    const int ntiles_tb = TB ? a.tb_nitems : 1;
+    const int wgx = TB ? (int)(blockIdx.x % ntiles_tb) : (int)blockIdx.x, tb = TB ? (int)(blockIdx.x / ntiles_tb) : 0;
+    const int NTg = TB ? a.tb_NT : a.NT;   // length of the grid the propagators are indexed by
+    const double2 *__restrict__ Upack = a.U + (size_t)(a.wg_gen ? a.wg_gen[wgx / (a.gen_div > 0 ? a.gen_div : 1)] : 0) * NTg * NP * NP;
     using GA = KrApplyGeom<NP>;
     constexpr int JQ = GA::JQA, JS = GA::JS, RT = GA::RT, SG = GA::SG, KTILE = SG * KT, NPP = NP + JQ, NW = GA::THREADS / 64;
     constexpr int CH = (KTILE * NP + 63) / 64;
     __shared__ __attribute__((aligned(16))) double2 sx[2][KTILE][NPP];
 
-    const int tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, wg = wgx, lane = tid & 63, wave = tid >> 6;
     const int team = tid / RT, tt = tid % RT, i = tt / JQ, jq = tt % JQ;
     const bool writer = (jq == 0), row_ok = (i < a.N);
     const bool memwave = (wave == NW - 1);
     const int pi_ = i + i / JS, xoff = jq * (JS + 1);
-    const int N = a.N, NT = a.NT;
+    const int N = a.N;
     const size_t slab = (size_t)a.Kp * N;
     const size_t tile_base = (size_t)wg * KTILE * N;
     const int tile_elems = KTILE * N;
+    // sweep positions: step s of this workgroup is position j0 + s of the sweep; NT = the steps it applies
+    const int j0 = TB ? tb * a.tb_S : 0;
+    const int NT = TB ? (((a.tb_S < NTg - j0) ? a.tb_S : (NTg - j0)) - 1) : a.NT;
+    const double2 *__restrict__ init = TB ? a.tb_bound + (size_t)tb * slab : a.init;
 
     int m_tq[CH], m_i[CH];
 #pragma unroll
@@ -149,14 +160,21 @@ __global__ __launch_bounds__((KrApplyGeom<NP>::THREADS), (KrApplyGeom<NP>::THREA
     for (int q = 0; q < KT; ++q) {
         const int tq = q * SG + team;
         double2 v = make_double2(0.0, 0.0);
-        if (row_ok) v = a.init[tile_base + (size_t)tq * N + i];
+        if (row_ok) v = init[tile_base + (size_t)tq * N + i];
         if (writer) sx[0][tq][pi_] = v;
     }
     if (memwave && a.store) {
-        const int slot0 = (a.dir > 0) ? 0 : NT;
+        const int slot0 = (a.dir > 0) ? j0 : NTg - j0;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-            if (m_tq[c] >= 0) a.store[(size_t)slot0 * slab + tile_base + lane + 64 * c] = a.init[tile_base + lane + 64 * c];
+            if (m_tq[c] >= 0) a.store[(size_t)slot0 * slab + tile_base + lane + 64 * c] = init[tile_base + lane + 64 * c];
+        if (TB && j0 + NT + 1 == NTg) {   // the last block: the final boundary into the last slot of the sweep
+            const int slotl = (a.dir > 0) ? NTg : 0;
+            const double2 *lastb = a.tb_bound + (size_t)(tb + 1) * slab;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (m_tq[c] >= 0) a.store[(size_t)slotl * slab + tile_base + lane + 64 * c] = lastb[tile_base + lane + 64 * c];
+        }
     }
     // Propagator slices: THREE register sets in rotation, the loop unrolled by three -- step k computes from set k % 3 while the
     // slice of step k + 2 lands in set (k + 2) % 3, whose contents step k - 1 has used up: two steps in flight, and no set is both
@@ -169,8 +187,9 @@ __global__ __launch_bounds__((KrApplyGeom<NP>::THREADS), (KrApplyGeom<NP>::THREA
     typedef double kr_v2d __attribute__((ext_vector_type(2)));   // (a vector type: asm register operands cannot be structs)
     kr_v2d u0[JS], u1[JS], u2[JS];
     auto slice_of = [&](const int step) {
-        const int sc = (step < NT) ? step : (NT - 1);
-        const int n = (a.dir > 0) ? sc : (NT - 1 - sc);
+        const int jp = j0 + step;
+        const int sc = (jp < NTg) ? jp : (NTg - 1);
+        const int n = (a.dir > 0) ? sc : (NTg - 1 - sc);
         return Upack + (size_t)n * NP * NP + tt;
     };
 #define KR_APPLY_FILL(set_, step_)                                                                                     \
@@ -199,7 +218,7 @@ __global__ __launch_bounds__((KrApplyGeom<NP>::THREADS), (KrApplyGeom<NP>::THREA
     int cur = 0;
 #define KR_APPLY_STEP(step_, use_, fill_)                                                                              \
     {                                                                                                                  \
-        const int n = (a.dir > 0) ? (step_) : (NT - 1 - (step_));                                                      \
+        const int n = (a.dir > 0) ? (j0 + (step_)) : (NTg - 1 - j0 - (step_));                                         \
         KR_APPLY_FILL(fill_, (step_) + 2)                                                                              \
         KR_APPLY_WAIT(use_)                                                                                            \
         double Ur[JS], Ui[JS];                                                                                         \
@@ -239,6 +258,72 @@ __global__ __launch_bounds__((KrApplyGeom<NP>::THREADS), (KrApplyGeom<NP>::THREA
                 a.fin[tile_base + lane + 64 * c] = sx[cur][m_tq[c]][ii + ii / JS];
             }
         }
+    }
+}
+
+// ---- block propagators of the time-blocked known-pulse sweeps, N <= 32 (round 5) ------------------------------
+// P_b = W_{j1 - 1} ... W_{j0}: the step propagators of sweep positions [j0, j1) = [b S, min((b + 1) S, N_T)), position j being
+// interval n = j (forward) or N_T - 1 - j (backward: U_d then holds the adjoint sweep's propagators), read and written in the
+// thread-major order of kr_sweep_apply (KrApplyGeom).  One workgroup per (generator, block); the running product and the next factor
+// live in LDS as plain matrices, the factor after that is already on its way (registers).  Grid = G x NB.
+template <int NP>
+__global__ __launch_bounds__(256, 1) void kr_tb_products_small(const KrSweepArgs a) {
+    static_assert(NP <= 32, "small state dimensions only (NP = 64: kr_device_tblock.h)");
+    using GA = KrApplyGeom<NP>;
+    constexpr int JQ = GA::JQA, JS = GA::JS, RT = GA::RT, EL = (NP * NP + 255) / 256, LD = NP + 1;
+    __shared__ double2 sR[2][NP * LD], sW[NP * LD];
+    const int tid = threadIdx.x;
+    const int NB = a.tb_NB, NTg = a.tb_NT, S = a.tb_S;
+    const int g = blockIdx.x / NB, b = blockIdx.x % NB;
+    const int j0 = b * S, j1 = (j0 + S < NTg) ? j0 + S : NTg;
+    const double2 *__restrict__ Ug = a.U + (size_t)g * NTg * NP * NP;
+    auto interval = [&](const int j) { return (a.dir > 0) ? j : (NTg - 1 - j); };
+    // element e of the thread-major pack is U[i][c] with:
+    auto row_of = [&](const int e) { return (e % RT) / JQ; };
+    auto col_of = [&](const int e) { return ((e % RT) % JQ) * JS + e / RT; };
+    double2 w[EL];
+#pragma unroll
+    for (int q = 0; q < EL; ++q) {
+        const int e = tid + 256 * q;
+        if (e < NP * NP) sR[0][row_of(e) * LD + col_of(e)] = Ug[(size_t)interval(j0) * NP * NP + e];
+    }
+    if (j0 + 1 < j1) {
+#pragma unroll
+        for (int q = 0; q < EL; ++q) { const int e = tid + 256 * q; if (e < NP * NP) w[q] = Ug[(size_t)interval(j0 + 1) * NP * NP + e]; }
+    }
+    int cur = 0;
+    for (int j = j0 + 1; j < j1; ++j) {
+#pragma unroll
+        for (int q = 0; q < EL; ++q) { const int e = tid + 256 * q; if (e < NP * NP) sW[row_of(e) * LD + col_of(e)] = w[q]; }
+        __syncthreads();   // (also: sR[cur] complete)
+        if (j + 1 < j1) {
+#pragma unroll
+            for (int q = 0; q < EL; ++q) { const int e = tid + 256 * q; if (e < NP * NP) w[q] = Ug[(size_t)interval(j + 1) * NP * NP + e]; }
+        }
+#pragma unroll
+        for (int q = 0; q < EL; ++q) {
+            const int e = tid + 256 * q;   // plain index here: row e / NP, column e % NP
+            if (e < NP * NP) {
+                const int i = e / NP, c = e % NP;
+                double yr = 0.0, yi = 0.0;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const double2 x = sW[i * LD + k], y = sR[cur][k * LD + c];
+                    yr = fma(x.x, y.x, yr); yr = fma(-x.y, y.y, yr);
+                    yi = fma(x.x, y.y, yi); yi = fma(x.y, y.x, yi);
+                }
+                sR[cur ^ 1][i * LD + c] = make_double2(yr, yi);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    __syncthreads();
+    double2 *__restrict__ out = a.tb_P + ((size_t)g * NB + b) * NP * NP;
+#pragma unroll
+    for (int q = 0; q < EL; ++q) {
+        const int e = tid + 256 * q;
+        if (e < NP * NP) out[e] = sR[cur][row_of(e) * LD + col_of(e)];
     }
 }
 

@@ -90,6 +90,7 @@ struct kr_handle {
     // known-pulse sweeps in blocks of time (kr_device_tblock.h, NP = 64): tb_S steps per block (0: sequential apply sweep), block
     // propagators [G][NB][4096], states at the block boundaries [NB + 1][Kp][N], the trajectory ranges a workgroup carries
     int tb_S = 0, tb_NB = 0, tb_nitems = 0;
+    bool tb_small = false;     // N <= 32: kr_tb_products_small + kr_sweep_apply<.., TB> (kr_device_prop.h) instead of the matrix-core kernels
     bool tb_tree = false;      // block propagators as a tree of pairwise products (tb_S a power of two), two ping-pong buffers of N_T / 2 matrices
     double2 *tb_P_d = nullptr, *tb_bound_d = nullptr, *tb_T_d[2] = {nullptr, nullptr};
     int *tb_items_d = nullptr;
@@ -1524,6 +1525,25 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
                 }
             }
         }
+        // N <= 32 (round 5, end): the same scheme on the vector kernels -- chain of products per block (kr_tb_products_small), the
+        // sequential apply sweep over the block propagators, the apply kernel once more with one workgroup per (block, tile).  A step
+        // of the sequential sweep is ~0.3 us of latency whatever N, so what pays is cutting N_T steps to N_T / S + S: S ~ sqrt(N_T).
+        // C2: 139 + 15 us per sweep -> see DESIGN.md 3.4.
+        if (h->precomp && NP <= 32 && NT >= opt_int(h, "TBLOCK_MIN_NT", 128)) {
+            int S = opt_int(h, "TBLOCK", -1);
+            // (measured, C2 per sweep [us] at S = 8 / 12 / 16 / 22 / 32 / 45 / 64: 52 / 49 / 48 / 51 / 57 / 65 / 79 -- the chain of S - 1 dependent
+            //  products per block weighs more than a step of the sweeps; N = 32, N_T = 1000, K = 64: 235 / 244 / 303 at 8 / 16 / 32, 500 without)
+            if (S < 0) { S = (int)std::lround(0.7 * std::sqrt((double)NT)); S = std::max(4, std::min(32, S)); }
+            if (S >= 2 && S <= 64 && NT >= 2 * S) {
+                const int NB = (NT + S - 1) / S;
+                const size_t bbytes = (size_t)(NB + 1) * h->Kp * N * sizeof(double2);
+                if (bbytes <= ((size_t)4 << 30)) {
+                    h->tb_S = S; h->tb_NB = NB; h->tb_small = true; h->tb_tree = false;
+                    CHK(dalloc(&h->tb_P_d, (size_t)G * NB * NP * NP));
+                    CHK(dalloc(&h->tb_bound_d, (size_t)(NB + 1) * h->Kp * N));
+                }
+            }
+        }
     }
     CHK(dalloc(&h->tau_d, h->Kp));
     CHK(dalloc(&h->tausum_d, 1));
@@ -1611,6 +1631,10 @@ static int one_create_impl(const kr_config *cfg, kr_handle **out, kr_handle *&li
         const char *known = h->gen_known ? "kr_gen_known" : h->rowsplit ? (h->rs_batch > 0 ? "kr_rowsplit_sweep in batches of launches" : "kr_rowsplit_sweep") : h->precomp ? "kr_expm + kr_sweep_apply" : "kr_sweep_known";
         char known_tb[160];
         if (h->tb_S > 0) {
+            if (h->tb_small)
+                snprintf(known_tb, sizeof known_tb, "time blocks (kr_expm_batch + kr_tb_products_small + kr_sweep_apply over %d block propagators + kr_sweep_apply per block, block length %d)",
+                         h->tb_NB, h->tb_S);
+            else
             snprintf(known_tb, sizeof known_tb, "time blocks on the matrix cores (kr_expm_mfma64 + %s + %s over %d block propagators + kr_tb_apply, block length %d)",
                      h->tb_tree ? "kr_tb_pair tree" : "kr_tb_products", h->mfma_sweep ? "kr_mf_apply_sweep" : "kr_sweep_apply", h->tb_NB, h->tb_S);
             known = known_tb;
@@ -2111,7 +2135,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         const bool mf_apply = h->NP == 64 && h->use_mfma && (mfa == 1 || (mfa == -1 && h->KT >= 2)) && (h->Kp % 2 == 0) &&
                               (h->G == 1 || h->KT % 2 == 0);
         const bool tb = h->tb_S > 0;   // blocks of time (kr_device_tblock.h)
-        a.u_layout = tb ? 2 : (mf_apply ? 1 : 0);
+        a.u_layout = (tb && !h->tb_small) ? 2 : (mf_apply ? 1 : 0);
         if (h->econ && h->NP == 64) {   // economized polynomial of every step (the pulses are known exactly: margin = rounding only;
                                         // smaller N: building the rows costs what the saved product gains -- C2 +6 us per sweep)
             const int rows = h->G * h->cfg.NT;
@@ -2122,7 +2146,7 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
         }
         HIPCHK(h, h->launch(h->LMAXv, std::min(h->KT, 4), 2, h->cfg.NT * h->G, h->stream, &a));
         // the sequential apply sweep over q.NT propagators q.U (the step propagators, or the block propagators of the time-blocked sweep)
-        auto apply_seq = [&](KrSweepArgs &q) -> int {
+        auto apply_seq = [&](KrSweepArgs &q, const int kind = 3, const int blocks = 1) -> int {   // (kind 7, blocks = NB: the parallel pass at N <= 32)
             if (mf_apply) {
                 int kt_a = (h->KT % 2 == 0) ? std::min(h->KT, 4) : 2;
                 const int want_a = opt_int(h, "MFMA_APPLY_KT", 0);   // (tuning knob: 2 or 4 trajectories per workgroup)
@@ -2144,12 +2168,29 @@ static int launch_known(kr_handle *h, int which_ev, const double *eps_dev, bool 
             }
             q.gen_div = h->KT * h->sets / kt_apply;   // apply tiles per update tile (wg_gen is indexed by update tile)
             if (q.gen_div < 1) q.gen_div = 1;
-            HIPCHK(h, h->launch(h->LMAXv, kt_apply, 3, h->Kp / (h->SG * kt_apply), h->stream, &q));
+            if (kind == 7) q.tb_nitems = h->Kp / (h->SG * kt_apply);
+            HIPCHK(h, h->launch(h->LMAXv, kt_apply, kind, blocks * (h->Kp / (h->SG * kt_apply)), h->stream, &q));
             return KR_OK;
         };
         if (!tb) {
             rc = apply_seq(a);
             if (rc) return rc;
+        } else if (h->tb_small) {
+            // N <= 32: (ii) one chain of products per (generator, block), (iii) the sequential sweep over the block propagators, (iv) the
+            // apply kernel again, one workgroup per (block, tile of trajectories), from the boundary states into the caller's storage
+            KrSweepArgs pa = a;
+            pa.tb_NT = h->cfg.NT; pa.tb_S = h->tb_S; pa.tb_NB = h->tb_NB; pa.tb_P = h->tb_P_d;
+            HIPCHK(h, h->launch(h->LMAXv, 1, 8, h->G * h->tb_NB, h->stream, &pa));
+            KrSweepArgs q = a;
+            q.U = h->tb_P_d; q.NT = h->tb_NB; q.dir = +1; q.store = h->tb_bound_d;
+            rc = apply_seq(q);
+            if (rc) return rc;
+            if (store) {
+                KrSweepArgs r = a;
+                r.tb_NT = h->cfg.NT; r.tb_S = h->tb_S; r.tb_NB = h->tb_NB; r.tb_bound = h->tb_bound_d; r.fin = nullptr;
+                rc = apply_seq(r, 7, h->tb_NB);
+                if (rc) return rc;
+            }
         } else {
             // (ii) block propagators, in the operand order of the sequential kernel that consumes them
             KrSweepArgs pa = a;

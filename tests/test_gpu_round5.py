@@ -129,7 +129,8 @@ def _nonherm(p, rng, N):
     p["H0"] = p["H0"] - 1j * 0.05 * np.diag(rng.uniform(0, 1, N)) + 0.02 * rng.normal(size=(N, N))
 
 
-@pytest.mark.parametrize("case", ["c3_shape", "ragged_nonherm_grid", "n40_k70", "two_generators", "matrix_cores_k600", "few_k3", "blocks_of_5", "blocks_of_8_chain", "blocks_of_4_tree", "blocks_of_32"])
+@pytest.mark.parametrize("case", ["c3_shape", "ragged_nonherm_grid", "n40_k70", "two_generators", "matrix_cores_k600", "few_k3", "blocks_of_5", "blocks_of_8_chain", "blocks_of_4_tree", "blocks_of_32",
+                                  "c2_shape", "small_two_generators_ragged", "n32_k300_three_controls", "n20_blocks_of_3", "n5_one_trajectory"])
 def test_known_pulse_sweeps_in_blocks_of_time_vs_oracle(case, oracle_c):
     """Round 5, kr_device_tblock.h: step propagators -> block propagators (matrix cores) -> sequential sweep over the block boundaries ->
     all blocks in parallel.  Forward storage (optimize.jl:254,263: slot n + 1), backward storage through the TRUE adjoint (optimize.jl:
@@ -137,7 +138,9 @@ def test_known_pulse_sweeps_in_blocks_of_time_vs_oracle(case, oracle_c):
     1e-11), for: C3's shape on a shorter grid, a ragged last block with a dissipative drift on a non-uniform grid, N < 64 with a
     trajectory count that fills neither a wave nor a workgroup, per-trajectory generators, the shapes whose sequential kernels run on
     the matrix cores, three trajectories, other block lengths, the block propagators as a tree of pairwise products (default, blocks of
-    16) or as a chain per block.  The sequential sweep (TBLOCK=0) must agree to rounding."""
+    16) or as a chain per block.  The sequential sweep (TBLOCK=0) must agree to rounding.
+    N <= 32 (kr_device_prop.h: kr_tb_products_small, kr_sweep_apply<.., TB>): C2's shape, per-trajectory generators on a ragged non-uniform
+    grid with a dissipative drift, several trajectories per workgroup, short blocks, a single trajectory."""
     rng = np.random.default_rng(5500)
     opts, tg, G = {}, None, 1
     if case == "c3_shape":
@@ -161,16 +164,28 @@ def test_known_pulse_sweeps_in_blocks_of_time_vs_oracle(case, oracle_c):
     elif case == "blocks_of_4_tree":
         N, NT, K, L = 50, 71, 130, 2
         opts["TBLOCK"] = 4
-    else:
+    elif case == "blocks_of_32":
         N, NT, K, L = 64, 150, 24, 1
         opts["TBLOCK"] = 32
+    elif case == "c2_shape":
+        N, NT, K, L = 16, 500, 32, 1
+    elif case == "small_two_generators_ragged":
+        N, NT, K, L = 7, 131, 19, 2
+        opts["TBLOCK"] = 6
+    elif case == "n32_k300_three_controls":
+        N, NT, K, L = 32, 150, 300, 3
+    elif case == "n20_blocks_of_3":
+        N, NT, K, L = 20, 40, 9, 2
+        opts.update(TBLOCK=3, TBLOCK_MIN_NT=16)
+    else:
+        N, NT, K, L = 5, 200, 1, 1
     p = wl.dense_problem(N, NT, K, L, 5501, 0.05, 2.0)
-    if case in ("ragged_nonherm_grid", "blocks_of_5"):
+    if case in ("ragged_nonherm_grid", "blocks_of_5", "small_two_generators_ragged"):
         _nonherm(p, rng, N)
         p["tlist"] = np.concatenate([[0.0], np.cumsum(np.diff(p["tlist"]) * rng.uniform(0.5, 1.5, NT))])
     H0, Hc = p["H0"], p["Hc"]
     kw = {}
-    if case == "two_generators":
+    if case in ("two_generators", "small_two_generators_ragged"):
         G = 2
         H0 = np.stack([p["H0"], 0.8 * p["H0"]])
         Hc = np.stack([p["Hc"], 1.2 * p["Hc"]])
@@ -180,7 +195,7 @@ def test_known_pulse_sweeps_in_blocks_of_time_vs_oracle(case, oracle_c):
     for name, o in (("blocks", dict(opts)), ("sequential", dict(opts, TBLOCK=0))):
         with kr.HipEngine(H0, Hc, p["tlist"], K, options=o, **kw) as eng:
             assert eng.info()["precomputed_propagators"] == 1, eng.plan()
-            assert ("time blocks on the matrix cores" in eng.plan()) == (name == "blocks"), eng.plan()
+            assert ("time blocks" in eng.plan()) == (name == "blocks") and ("on the matrix cores" in eng.plan()) == (name == "blocks" and N > 32), eng.plan()
             eng.set_initial_states(p["psi0"])
             psiT = eng.forward(p["eps"])
             fw = np.stack([np.stack([eng.read_storage("fw", k, n) for k in (0, K // 2, K - 1)]) for n in range(NT + 1)])
